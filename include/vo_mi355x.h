@@ -1,0 +1,215 @@
+/*
+ * vo_mi355x.h -- C ABI of libvo_mi355x.so, the MI355X (gfx950) implementation of the
+ * per-frame-pair visual-odometry front end of Elektron97/Visual_Odometry.
+ *
+ * The reference has no FFI/plugin interface: its boundary is three header-defined free
+ * functions taking OpenCV value types.  Every entry point below names the
+ * reference call it replaces (path:line under the reference checkout).  All buffers are
+ * caller owned, sizes are explicit, no exception crosses the boundary: every function
+ * returns VO_OK (0) or a negative vo_status; vo_strerror() gives the text.
+ *
+ * Images are passed exactly as cv::Mat exposes them: (data, rows, cols, step_bytes) of a
+ * CV_8UC1 matrix.  3x3 / 3x4 matrices are row-major doubles (cv::Mat1d layout).  Point
+ * arrays are interleaved float xy (std::vector<cv::Point2f> layout).
+ *
+ * A vo_ctx owns one HIP device, its streams and all device scratch.  It is NOT thread-safe:
+ * use one context per host thread / GPU.  There is no CPU fallback: if the HIP runtime or a
+ * gfx950 device is missing, vo_ctx_create fails with VO_ERR_NO_DEVICE.
+ */
+#ifndef VO_MI355X_H
+#define VO_MI355X_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VO_ABI_VERSION 1
+
+typedef enum vo_status {
+    VO_OK = 0,
+    VO_ERR_INVALID_ARG = -1,   /* null pointer, non-positive size, bad step            */
+    VO_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 / device index out of range */
+    VO_ERR_HIP = -3,           /* a HIP runtime call failed (see vo_last_hip_error)   */
+    VO_ERR_CAPACITY = -4,      /* an output did not fit the caller's capacity          */
+    VO_ERR_UNSUPPORTED = -5,   /* parameter combination not implemented (e.g. extended)*/
+    VO_ERR_TOO_FEW_POINTS = -6,/* fewer than 5 correspondences (findEssentialMat fails)*/
+    VO_ERR_NO_MODEL = -7       /* RANSAC found no model with more than 4 inliers       */
+} vo_status;
+
+/* cv::KeyPoint mirror (pt.x, pt.y, size, angle, response, octave, class_id): 28 bytes.  */
+typedef struct vo_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} vo_keypoint;
+
+/* cv::DMatch mirror (queryIdx, trainIdx, imgIdx, distance).                             */
+typedef struct vo_dmatch {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} vo_dmatch;
+
+/* enum fail_V0 of the node: src/visual_Odometry.cpp:58                                  */
+typedef enum vo_fail { VO_FAIL_DETECTION = 0, VO_NOT_MOVING = 1, VO_FAIL_RECOVER = 2, VO_SUCCESS = 3 } vo_fail;
+
+/*
+ * Algorithm parameters.  In the reference these are header globals
+ * (include/visual_odometry/camera_utility.hpp:11-13, 33-63); vo_params_default() fills the
+ * same values.  The ROI of the reference (28/20/614/482) is tied to its 640x505 frames, so
+ * it is a parameter here.
+ */
+typedef struct vo_params {
+    float hessian_threshold;      /* minHessian = 50                       :33 */
+    int32_t n_octaves;            /* 4                                     :35 */
+    int32_t n_octave_layers;      /* 3                                     :36 */
+    int32_t extended;             /* false (64 floats)                     :37 */
+    int32_t upright;              /* false                                 :38 */
+    float ratio_thresh;           /* 0.7f                                  :41 */
+    float roi_x_lo, roi_y_lo;     /* width_low = 28, height_low = 20       :44-45 */
+    float roi_x_hi, roi_y_hi;     /* width_high = 614, height_high = 482   :46-47 */
+    double ransac_prob;           /* 0.99                                  :53 */
+    double ransac_threshold;      /* 2.0 px                                :54 */
+    int32_t ransac_max_iters;     /* 1000 (7-argument findEssentialMat)        */
+    uint64_t ransac_seed;         /* cv::RNG((uint64)-1) inside the registrator */
+    float inlier_threshold;       /* 0.3                                   :56 */
+    float vpf_threshold;          /* 0.85                                  :58 */
+    double distance_threshold;    /* 50.0 (recoverPose 6-arg default)      :60 */
+    float reprojection_tolerance; /* 0.5 px                                :63 */
+    int32_t kp_capacity;          /* max keypoints per frame kept on device (default 16384) */
+    int32_t match_capacity;       /* max matches per pair (default = kp_capacity)           */
+} vo_params;
+
+typedef struct vo_ctx vo_ctx;
+typedef struct vo_batch vo_batch;
+
+int vo_abi_version(void);
+const char* vo_strerror(int status);
+/* text of the last failing HIP call on this thread ("" if none) */
+const char* vo_last_hip_error(void);
+void vo_params_default(vo_params* p);
+
+/* Context: one per GPU / host thread.  params may be NULL (defaults).                  */
+int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** out);
+void vo_ctx_destroy(vo_ctx* ctx);
+int vo_ctx_get_params(const vo_ctx* ctx, vo_params* out);
+
+/* ---- a1-a2 (test / inspection entry points; the product path fuses a2 into a3) ------ */
+/* cv::integral(img, sum, CV_32S) inside SURF detectAndCompute (camera_utility.hpp:749).
+ * sum is (rows+1)*(cols+1) int32, row-major.                                            */
+int vo_integral(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step, int32_t* sum);
+/* Fast-Hessian det/trace of one of the 20 layers (octave 0..3, layer 0..4).  Output
+ * arrays are (rows/step_o)*(cols/step_o) floats; untouched border samples are 0.         */
+int vo_hessian_layer(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step,
+                     int octave, int layer, float* det, float* trace);
+
+/* ---- a1-a6: SURF::create(50,4,3,false,false)->detectAndCompute(img, noArray(), kps, desc)
+ * camera_utility.hpp:746-750.  kps/desc64 hold up to cap entries; *n = count written.
+ * Keypoints come out in OpenCV's KeypointGreater order.  desc64 may be NULL (detect only:
+ * angle is then -1 as after fastHessianDetector).                                       */
+int vo_detect_describe(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step,
+                       vo_keypoint* kps, float* desc64, int cap, int* n);
+
+/* ---- a7: knnMatch(desc1, desc2, knn, 2), exact brute-force L2 (camera_utility.hpp:759-762;
+ * the reference uses FLANN, the "OLD METHOD" :752-755 and the north star are brute force).
+ * idx2/dist2 are [nA][2]; dist = sqrt(sum (a-b)^2), ties to the lower train index.       */
+int vo_match_knn2(vo_ctx* ctx, const float* descA, int nA, const float* descB, int nB,
+                  int32_t* idx2, float* dist2);
+
+/* ---- a1-a9: opt_DetectFeatures(img1, img2, kP) camera_utility.hpp:742-809.
+ * p1xy/p2xy: matched keypoint positions (kP.Kpoints1/2), m: kP.match, all up to cap.     */
+int vo_detect_match(vo_ctx* ctx, const uint8_t* img1, size_t step1, const uint8_t* img2, size_t step2,
+                    int rows, int cols, float* p1xy, float* p2xy, vo_dmatch* m, int cap, int* n);
+
+/* ---- a10: findEssentialMat(p1, p2, K, RANSAC, prob, thr, mask) camera_utility.hpp:642.
+ * mask is n bytes of 0/1.  *n_inl = inlier count, *iters_run = hypotheses consumed by the
+ * sequential-equivalent loop (may be NULL).                                              */
+int vo_essential_ransac(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, const double K[9],
+                        double prob, double thr_px, int max_iters, uint64_t seed,
+                        double E[9], uint8_t* mask, int* n_inl, int* iters_run);
+
+/* The deterministic 5-tuples the registrator draws (cv::RNG stream).
+ * idx5 is [n_tuples][5].  Pure host logic, no GPU needed.                               */
+int vo_ransac_subsets(uint64_t seed, int count, int n_tuples, int32_t* idx5);
+
+/* Nister five-point solver for explicit 5-tuples (test entry point for "one wavefront per
+ * hypothesis").  pts are normalised coordinates, [n_hyp][5][2] doubles for each image.
+ * E_out [n_hyp][10][9], n_models [n_hyp]; candidates ordered by ascending real root z.   */
+int vo_five_point(vo_ctx* ctx, const double* x1, const double* x2, int n_hyp,
+                  double* E_out, int32_t* n_models);
+
+/* Sampson scoring of given models (EMEstimatorCallback::computeError + findInliers).
+ * pts are PIXEL coordinates; masks [n_models][n] bytes, counts [n_models].               */
+int vo_sampson_masks(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, const double K[9],
+                     double thr_px, const double* E, int n_models, uint8_t* masks, int32_t* counts);
+
+/* ---- a12: recoverPose(E, inl1, inl2, K, R, t) camera_utility.hpp:667                  */
+int vo_recover_pose(vo_ctx* ctx, const double E[9], const float* p1xy, const float* p2xy, int n,
+                    const double K[9], double dist_thresh, double R[9], double t[3], int* n_good);
+
+/* ---- a10-a12 + gates: optRelativePose(kP, K, R, t, inlier, success) camera_utility.hpp:633-685.
+ * R_io/t_io are overwritten only on success.  in1xy/in2xy need room for n points.        */
+int vo_relative_pose(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, const double K[9],
+                     double R_io[9], double t_io[3], float* in1xy, float* in2xy, int* n_inl, int* success);
+
+/* ---- a13: triangulatePoints(P0, P1, pts1, pts2, X4) camera_utility.hpp:320.
+ * X4 is [4][n] row-major CV_32F, unit 4-vectors (sign arbitrary).                        */
+int vo_triangulate(vo_ctx* ctx, const double P0[12], const double P1[12],
+                   const float* p1xy, const float* p2xy, int n, float* X4);
+
+/* ---- a13-a14: triangPoints(inl1, inl2, R, t, K) camera_utility.hpp:288-351.
+ * Xk is [3][cap] row-major doubles (column j = point j, frame {k}); *m = points kept.    */
+int vo_triang_points(vo_ctx* ctx, const float* in1xy, const float* in2xy, int n,
+                     const double R[9], const double t[3], const double K[9],
+                     double* Xk, int cap, int* m);
+
+/* ---- batched, device-resident pipeline: all pairs of a batch run through
+ * detect x2 -> match -> E-RANSAC -> recoverPose -> triangulate with no host round trip.  */
+typedef struct vo_pair_out {
+    int32_t status;         /* vo_status of this pair                                    */
+    int32_t n_kp1, n_kp2;   /* keypoints per frame                                       */
+    int32_t n_match;        /* matches after ratio + ROI                                 */
+    int32_t n_inl;          /* RANSAC inliers                                            */
+    int32_t n_good;         /* recoverPose cheirality count                              */
+    int32_t n_world;        /* triangulated points kept                                  */
+    int32_t success;        /* optRelativePose success flag                              */
+    int32_t iters;          /* RANSAC hypotheses consumed                                */
+    int32_t pad_;
+    double E[9];
+    double R[9];
+    double t[3];
+} vo_pair_out;
+
+int vo_batch_create(vo_ctx* ctx, int n_pairs, int rows, int cols, vo_batch** out);
+void vo_batch_destroy(vo_batch* b);
+/* copy one pair's frames host -> device (asynchronous on the batch's copy stream)       */
+int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, size_t step1,
+                      const uint8_t* img2, size_t step2, const double K[9]);
+/* enqueue the whole pipeline for all pairs; returns without waiting                     */
+int vo_batch_run(vo_batch* b);
+int vo_batch_sync(vo_batch* b);
+int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out);
+/* optional bulk outputs of a finished pair (any pointer may be NULL)                    */
+int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask,
+                        int cap, double* Xk, int cap_world);
+
+/* Per-stage device timing (HIP events on the context's compute stream).  Enable, run,
+ * sync, then read.  Stage names: vo_stage_name(i), i in [0, vo_stage_count()).           */
+int vo_profile_enable(vo_ctx* ctx, int on);
+int vo_stage_count(void);
+const char* vo_stage_name(int stage);
+/* accumulated milliseconds and launch count of a stage since the last reset             */
+int vo_profile_get(vo_ctx* ctx, int stage, double* ms, int64_t* launches);
+int vo_profile_reset(vo_ctx* ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VO_MI355X_H */

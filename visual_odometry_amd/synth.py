@@ -1,0 +1,152 @@
+"""Deterministic synthetic inputs for the VO front end.
+
+"Blob scenes": 3-D points seen from two camera poses, each rendered as an isotropic Gaussian spot on a
+flat background plus low-amplitude band-limited noise.  The reference ships no data (its rosbags are
+not in the repository, launch/*.launch:8), so every test and benchmark input comes from here.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+# intrinsics of the reference's two YAML files (config/camera_intrinsic.yaml:2-5,
+# config/rapallo_intrinsic.yaml:2-6 scaled to its 640x505 desired_size)
+K_PARETE = np.array([[407.0646129842357, 0.0, 384.5], [0.0, 407.0646129842357, 246.5], [0.0, 0.0, 1.0]])
+K_1080P = np.array([[1400.0, 0.0, 959.5], [0.0, 1400.0, 539.5], [0.0, 0.0, 1.0]])
+K_4K = np.array([[2800.0, 0.0, 1919.5], [0.0, 2800.0, 1079.5], [0.0, 0.0, 1.0]])
+
+
+def rodrigues(rvec: np.ndarray) -> np.ndarray:
+    th = float(np.linalg.norm(rvec))
+    if th < 1e-15:
+        return np.eye(3)
+    k = rvec / th
+    Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+    return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * (Kx @ Kx)
+
+
+@dataclasses.dataclass
+class Scene:
+    img1: np.ndarray  # uint8 [H, W]
+    img2: np.ndarray
+    K: np.ndarray  # 3x3 float64
+    R: np.ndarray  # X2 = R @ X1 + t
+    t: np.ndarray  # unit 3-vector
+    pts3d: np.ndarray  # [P, 3] in frame 1
+
+
+def _value_noise(rng: np.random.Generator, h: int, w: int, cell: int, amp: float) -> np.ndarray:
+    gh, gw = h // cell + 2, w // cell + 2
+    g = rng.uniform(-amp, amp, size=(gh, gw))
+    ys = np.arange(h) / cell
+    xs = np.arange(w) / cell
+    y0 = ys.astype(np.int64)
+    x0 = xs.astype(np.int64)
+    fy = (ys - y0)[:, None]
+    fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]
+    b = g[y0][:, x0 + 1]
+    c = g[y0 + 1][:, x0]
+    d = g[y0 + 1][:, x0 + 1]
+    return a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx
+
+
+def _render(h: int, w: int, uv: np.ndarray, sigma: np.ndarray, amp: np.ndarray, noise: np.ndarray) -> np.ndarray:
+    img = np.full((h, w), 128.0) + noise
+    for (u, v), s, a in zip(uv, sigma, amp):
+        r = int(np.ceil(3.5 * s)) + 1
+        x0, x1 = int(np.floor(u)) - r, int(np.floor(u)) + r + 1
+        y0, y1 = int(np.floor(v)) - r, int(np.floor(v)) + r + 1
+        if x1 <= 0 or y1 <= 0 or x0 >= w or y0 >= h:
+            continue
+        x0c, x1c, y0c, y1c = max(x0, 0), min(x1, w), max(y0, 0), min(y1, h)
+        xs = np.arange(x0c, x1c) - u
+        ys = np.arange(y0c, y1c) - v
+        gx = np.exp(-0.5 * (xs / s) ** 2)
+        gy = np.exp(-0.5 * (ys / s) ** 2)
+        img[y0c:y1c, x0c:x1c] += a * gy[:, None] * gx[None, :]
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def blob_scene(
+    h: int,
+    w: int,
+    K: np.ndarray,
+    n_blobs: int,
+    seed: int,
+    rot_deg: float = 3.0,
+    baseline: float = 0.3,
+    depth=(3.0, 12.0),
+    sigma_px=(1.6, 7.0),
+    noise_amp: float = 2.0,
+    noise_cell: int = 6,
+) -> Scene:
+    """Two views of n_blobs random 3-D points.  View 2 = (R, t) with rotvec ~ U(-rot_deg, rot_deg)^3 and
+    |t| = baseline (returned t is the unit direction, as recoverPose reports it)."""
+    rng = np.random.default_rng(seed)
+    rvec = np.deg2rad(rng.uniform(-rot_deg, rot_deg, size=3))
+    R = rodrigues(rvec)
+    tdir = rng.normal(size=3)
+    tdir /= np.linalg.norm(tdir)
+    t = tdir * baseline
+    # features: uniform pixels in an enlarged view-1 frame, depth uniform.  Each feature is a main spot
+    # plus two satellites at fixed 3-D offsets (same depth), so it has a dominant orientation and an
+    # asymmetric neighbourhood: isotropic spots alone give SURF no repeatable orientation.
+    m = 0.08
+    u = rng.uniform(-m * w, (1 + m) * w, size=n_blobs)
+    v = rng.uniform(-m * h, (1 + m) * h, size=n_blobs)
+    z = rng.uniform(depth[0], depth[1], size=n_blobs)
+    s1 = np.exp(rng.uniform(np.log(sigma_px[0]), np.log(sigma_px[1]), size=n_blobs))
+    amp = rng.uniform(30.0, 90.0, size=n_blobs) * rng.choice([-1.0, 1.0], size=n_blobs)
+    phi = rng.uniform(0, 2 * np.pi, size=n_blobs)
+    du = np.concatenate([np.zeros(n_blobs), 1.8 * s1 * np.cos(phi), 2.2 * s1 * np.cos(phi + 2.1)])
+    dv = np.concatenate([np.zeros(n_blobs), 1.8 * s1 * np.sin(phi), 2.2 * s1 * np.sin(phi + 2.1)])
+    ua, va, za = np.tile(u, 3) + du, np.tile(v, 3) + dv, np.tile(z, 3)
+    sa = np.concatenate([s1, 0.7 * s1, 0.6 * s1])
+    aa = np.concatenate([amp, 0.7 * amp, -0.5 * amp])
+    Kinv = np.linalg.inv(K)
+    Xa = (Kinv @ np.stack([ua, va, np.ones_like(ua)])) * za  # [3, 3P]
+    Xb = R @ Xa + t[:, None]
+    uvb = (K @ Xb)[:2] / Xb[2]
+    sb = sa * za / Xb[2]
+    n1 = _value_noise(rng, h, w, noise_cell, noise_amp)
+    n2 = _value_noise(rng, h, w, noise_cell, noise_amp)
+    img1 = _render(h, w, np.stack([ua, va], 1), sa, aa, n1)
+    img2 = _render(h, w, uvb.T, sb, aa, n2)
+    X1 = Xa[:, :n_blobs]
+    return Scene(img1, img2, K.copy(), R, tdir, X1.T.copy())
+
+
+def correspondences(
+    n: int, K: np.ndarray, seed: int, inlier_frac: float = 0.5, noise_px: float = 0.5, h: int = 1080, w: int = 1920,
+    rot_deg: float = 5.0, depth=(4.0, 20.0)
+):
+    """C5-style synthetic matches: inliers from a known pose (+ pixel noise), outliers uniform in the image.
+    Returns p1 [n,2] f32, p2 [n,2] f32, R, t(unit), inlier flags."""
+    rng = np.random.default_rng(seed)
+    R = rodrigues(np.deg2rad(rng.uniform(-rot_deg, rot_deg, size=3)))
+    t = rng.normal(size=3)
+    t /= np.linalg.norm(t)
+    u = rng.uniform(0, w, size=n)
+    v = rng.uniform(0, h, size=n)
+    z = rng.uniform(depth[0], depth[1], size=n)
+    X1 = (np.linalg.inv(K) @ np.stack([u, v, np.ones(n)])) * z
+    X2 = R @ X1 + t[:, None]
+    uv2 = ((K @ X2)[:2] / X2[2]).T
+    p1 = np.stack([u, v], 1) + rng.normal(0, noise_px, size=(n, 2))
+    p2 = uv2 + rng.normal(0, noise_px, size=(n, 2))
+    is_in = rng.uniform(size=n) < inlier_frac
+    out2 = np.stack([rng.uniform(0, w, size=n), rng.uniform(0, h, size=n)], 1)
+    p2 = np.where(is_in[:, None], p2, out2)
+    return p1.astype(np.float32), p2.astype(np.float32), R, t, is_in
+
+
+def surf_like_descriptors(n: int, seed: int) -> np.ndarray:
+    """[n,64] f32 unit vectors with SURF-like statistics (signed sums and absolute sums per cell)."""
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n, 16, 4))
+    d[:, :, 2:] = np.abs(d[:, :, 2:]) + np.abs(d[:, :, :2])
+    d = d.reshape(n, 64)
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    return d.astype(np.float32)
