@@ -1,0 +1,83 @@
+"""GPU parity: SURF detect + describe through the C ABI vs the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from visual_odometry_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _scene(h, w, nb, seed, K=None):
+    return synth.blob_scene(h, w, synth.K_PARETE if K is None else K, nb, seed)
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (505, 640), (97, 131), (64, 64)])
+def test_integral_exact(ctx, shape):
+    rng = np.random.default_rng(shape[0])
+    img = rng.integers(0, 256, size=shape, dtype=np.uint8)
+    got = ctx.integral(img)
+    ref = O.integral(img)
+    assert np.array_equal(got, ref)
+    # independent of the oracle: numpy cumulative sums
+    ref2 = np.zeros((shape[0] + 1, shape[1] + 1), np.int64)
+    ref2[1:, 1:] = img.astype(np.int64).cumsum(0).cumsum(1)
+    assert np.array_equal(got.astype(np.int64), ref2)
+
+
+def test_integral_strided_and_saturated(ctx):
+    big = np.full((300, 700), 255, np.uint8)
+    view = big[:, 3:643]  # step != cols
+    assert np.array_equal(ctx.integral(view), O.integral(np.ascontiguousarray(view)))
+
+
+@pytest.mark.parametrize("octave,layer", [(0, 0), (0, 2), (0, 4), (1, 1), (1, 4), (2, 0), (2, 3), (3, 2), (3, 4)])
+def test_hessian_layers_bit_exact(ctx, octave, layer):
+    sc = _scene(480, 640, 500, 11)
+    det, tr = ctx.hessian_layer(sc.img1, octave, layer)
+    rdet, rtr = O.hessian_layer(sc.img1, octave, layer)
+    assert np.array_equal(det.view(np.uint32), rdet.view(np.uint32))
+    assert np.array_equal(tr.view(np.uint32), rtr.view(np.uint32))
+
+
+def _assert_kps_equal(k, rk):
+    assert len(k) == len(rk)
+    for f in ("x", "y", "size", "response", "octave", "class_id"):
+        assert np.array_equal(k[f], rk[f]), f
+
+
+@pytest.mark.parametrize("shape,nb,seed", [((480, 640), 700, 1001), ((505, 640), 500, 3003), ((240, 320), 150, 7)])
+def test_keypoints_exact(ctx, shape, nb, seed):
+    sc = _scene(shape[0], shape[1], nb, seed)
+    k, _ = ctx.detect_describe(sc.img1, describe=False)
+    rk, _ = O.detect_describe(sc.img1, describe=False)
+    _assert_kps_equal(k, rk)
+    assert np.all(k["angle"] == -1)
+
+
+@pytest.mark.parametrize("shape,nb,seed", [((480, 640), 700, 1001), ((505, 640), 500, 3003)])
+def test_descriptors_exact(ctx, shape, nb, seed):
+    sc = _scene(shape[0], shape[1], nb, seed)
+    for img in (sc.img1, sc.img2):
+        k, d = ctx.detect_describe(img)
+        rk, rd = O.detect_describe(img)
+        _assert_kps_equal(k, rk)
+        assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+        # bit-exact: same operation order, -ffp-contract=off on both sides
+        bad = np.flatnonzero((d.view(np.uint32) != rd.view(np.uint32)).any(axis=1))
+        assert len(bad) == 0, (len(bad), len(k), bad[:10], np.abs(d - rd).max())
+
+
+def test_uniform_image_has_no_keypoints(ctx):
+    img = np.full((200, 300), 77, np.uint8)
+    k, d = ctx.detect_describe(img)
+    assert len(k) == 0 and d.shape == (0, 64)
+
+
+def test_capacity_error(ctx):
+    from visual_odometry_amd.frontend import VoError
+
+    sc = _scene(480, 640, 700, 1001)
+    with pytest.raises(VoError) as e:
+        ctx.detect_describe(sc.img1, cap=10)
+    assert e.value.status == -4

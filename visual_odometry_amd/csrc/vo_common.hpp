@@ -1,0 +1,210 @@
+// Internal declarations of libvo_mi355x.so (gfx950 only; no CPU fallback, no dual paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/vo_mi355x.h"
+
+// ---------------------------------------------------------------- errors
+void vo_set_hip_error(const char* what, hipError_t e, const char* file, int line);
+#define VO_HIP(call)                                             \
+    do {                                                         \
+        hipError_t e_ = (call);                                  \
+        if (e_ != hipSuccess) {                                  \
+            vo_set_hip_error(#call, e_, __FILE__, __LINE__);     \
+            return VO_ERR_HIP;                                   \
+        }                                                        \
+    } while (0)
+#define VO_TRY(call)               \
+    do {                           \
+        int s_ = (call);           \
+        if (s_ != VO_OK) return s_; \
+    } while (0)
+
+// ---------------------------------------------------------------- constants of the algorithm
+constexpr int kNumOctaves = 4;
+constexpr int kLayersPerOctave = 5;  // nOctaveLayers + 2
+constexpr int kNumLayers = kNumOctaves * kLayersPerOctave;
+constexpr int kOriSamples = 109;  // grid points with i^2 + j^2 <= 36
+constexpr int kPatch = 20;        // PATCH_SZ
+constexpr int kMaxHyp = 4096;     // largest max_iters accepted (BASELINE config 5)
+constexpr int kMaxModels = 10;
+
+// Box pattern of one fast-Hessian layer, edges shared between adjacent boxes.
+struct LayerTab {
+    int size, step, margin, pad0;
+    int xdx[4], ydx[2];  // Dx: 3 boxes side by side in x
+    int xdy[2], ydy[4];  // Dy: 3 boxes stacked in y
+    int cxy[4];          // Dxy: edges {1,4,5,8} scaled, same for x and y
+    float w[10];         // weights: Dx[3], Dy[3], Dxy[4]
+    float pad1[2];
+};
+
+struct DetectTables {
+    LayerTab layers[kNumLayers];
+    int aptx[kOriSamples + 3], apty[kOriSamples + 3];
+    float aptw[kOriSamples + 3];
+    float DW[kPatch * kPatch];
+};
+
+// per-frame device counters
+struct FrameCounters {
+    int n_raw;    // keypoints appended by NMS (may exceed capacity)
+    int n_kp;     // min(n_raw, cap): keypoints in the sorted list
+    int pad[2];
+};
+
+// per-pair device state of matching + geometry
+struct PairState {
+    int n_match;       // matches after ratio + ROI (may exceed capacity -> clipped in n_used)
+    int n_used;        // min(n_match, match_cap)
+    int niters;        // current RANSAC iteration bound (sequential semantics)
+    int best_count;    // maxGoodCount
+    int best_hyp;      // hypothesis index of the best model (-1 none)
+    int best_model;    // model index within the hypothesis
+    int scanned;       // hypotheses already consumed by the in-order scan
+    int n_inl;
+    int good[4];       // cheirality counts of the 4 pose candidates
+    int n_good;
+    int success;
+    int status;
+    int n_pre;         // triangulated points passing reprojection + Z>0
+    int n_world;
+    int iters_run;
+    int pad[2];
+    double K[9];
+    double E[9];
+    double R[9];       // in/out pose (identity / zero before the first success)
+    double t[3];
+    double Rc[2][9];   // decomposeEssentialMat candidates
+    double tc[3];
+    double zstat[2];   // mean / variance of Z for the 3-sigma filter
+};
+
+// ---------------------------------------------------------------- profiling stages
+enum Stage {
+    ST_INTEGRAL = 0,
+    ST_HESSIAN_NMS,
+    ST_SORT,
+    ST_DESCRIBE,
+    ST_MATCH_PREP,
+    ST_MATCH_MFMA,
+    ST_MATCH_SELECT,
+    ST_RANSAC_SAMPLE,
+    ST_RANSAC_SOLVE_SCORE,
+    ST_RANSAC_SELECT,
+    ST_POSE,
+    ST_TRIANGULATE,
+    ST_COUNT
+};
+
+struct StageTimer {
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;  // events of unresolved launches
+    double ms = 0;
+    int64_t launches = 0;
+};
+
+// ---------------------------------------------------------------- device buffers
+struct FrameSet {
+    int F = 0, H = 0, W = 0, cap = 0;
+    uint8_t* img = nullptr;      // [F][H][W]
+    int32_t* sum = nullptr;      // [F][H+1][W+1]
+    int32_t* colsum = nullptr;   // [F][nbands][W]
+    vo_keypoint* kp_raw = nullptr;  // [F][cap]
+    vo_keypoint* kp = nullptr;      // [F][cap] sorted
+    int* rank = nullptr;            // [F][cap]
+    float* desc = nullptr;          // [F][cap][64]
+    float* descT = nullptr;         // [F][cap/32][8][64][4] MFMA operand layout + norms
+    float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
+    FrameCounters* cnt = nullptr;   // [F]
+    size_t img_stride() const { return (size_t)H * W; }
+    size_t sum_stride() const { return (size_t)(H + 1) * (W + 1); }
+};
+
+struct PairSet {
+    int P = 0, kp_cap = 0, match_cap = 0, max_hyp = 0;
+    int n_split = 0;            // train-range splits of the MFMA pass
+    float* cand_val = nullptr;  // [P][kp_cap][n_split*4]
+    int* cand_idx = nullptr;
+    int* knn_idx = nullptr;     // [P][kp_cap][2]
+    float* knn_dist = nullptr;  // [P][kp_cap][2]
+    float* p1 = nullptr;        // [P][match_cap][2]
+    float* p2 = nullptr;
+    vo_dmatch* matches = nullptr;  // [P][match_cap]
+    double* m1 = nullptr;       // [P][match_cap][2] normalised
+    double* m2 = nullptr;
+    int* tuples = nullptr;      // [P][max_hyp][5]
+    double* models = nullptr;   // [P][max_hyp][10][9]
+    int* nmodels = nullptr;     // [P][max_hyp]
+    int* counts = nullptr;      // [P][max_hyp][10]
+    uint8_t* mask = nullptr;    // [P][match_cap]
+    float* in1 = nullptr;       // [P][match_cap][2] inliers
+    float* in2 = nullptr;
+    float* X4 = nullptr;        // [P][4][match_cap]
+    double* Xpre = nullptr;     // [P][match_cap][3] points passing the reprojection filter (frame k)
+    double* Xk = nullptr;       // [P][3][match_cap]
+    PairState* st = nullptr;    // [P]
+};
+
+struct vo_ctx {
+    vo_params prm;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    DetectTables* d_tables = nullptr;
+    uint32_t* d_rng_raw = nullptr;  // unused placeholder (rng stream is generated on device)
+    bool profiling = false;
+    StageTimer timers[ST_COUNT];
+    // lazily sized scratch for the single-call entry points
+    FrameSet fs;
+    PairSet ps;
+    void* d_tmp = nullptr;
+    size_t d_tmp_bytes = 0;
+};
+
+struct vo_batch {
+    vo_ctx* ctx = nullptr;
+    int n_pairs = 0, rows = 0, cols = 0;
+    FrameSet fs;  // 2 * n_pairs frames: frame 2p = img1 of pair p, 2p+1 = img2
+    PairSet ps;
+};
+
+// ---------------------------------------------------------------- helpers (vo_api.cpp)
+int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap);
+void vo_frameset_free(FrameSet& fs);
+int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp);
+void vo_pairset_free(PairSet& ps);
+int vo_ctx_tmp(vo_ctx* ctx, size_t bytes, void** out);
+
+struct StageScope {  // records HIP events around a stage when profiling is on
+    vo_ctx* ctx;
+    int stage;
+    hipEvent_t a = nullptr, b = nullptr;
+    StageScope(vo_ctx* c, int s);
+    ~StageScope();
+};
+
+// ---------------------------------------------------------------- kernels' host launchers
+// vo_detect.hip
+void vo_build_detect_tables(DetectTables& t, int sum_cols_unused);
+int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs);
+int vo_enqueue_hessian_layer(vo_ctx* ctx, FrameSet& fs, int frame, int octave, int layer, float* d_det, float* d_trace);
+int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe);
+// vo_match.hip
+int vo_enqueue_match_prep(vo_ctx* ctx, const float* d_desc, size_t desc_stride, const FrameCounters* cnt, int cnt_step,
+                          int cnt_first, int nsets, int cap, float* d_descT, float* d_nrm);
+int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter);
+// vo_geometry.hip
+int vo_enqueue_relative_pose(vo_ctx* ctx, PairSet& ps, bool run_ransac, bool run_pose, bool run_triang);
+int vo_enqueue_five_point(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n_hyp, double* d_E, int* d_nm);
+int vo_enqueue_sampson_masks(vo_ctx* ctx, const double* d_m1, const double* d_m2, int n, double thr_norm,
+                             const double* d_E, int n_models, uint8_t* d_masks, int* d_counts);
+int vo_enqueue_normalise(vo_ctx* ctx, const float* d_p, int n, const double* d_K, double* d_m);
+int vo_enqueue_triangulate(vo_ctx* ctx, const double* d_P0, const double* d_P1, const float* d_p1, const float* d_p2, int n,
+                           float* d_X4);
+int vo_upload_detect_tables(const DetectTables& t);
+int vo_geometry_init(vo_ctx* ctx);

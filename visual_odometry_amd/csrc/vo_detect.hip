@@ -1,0 +1,913 @@
+// SURF detect + describe for gfx950.
+//
+// Replaces SURF::create(50,4,3,false,false)->detectAndCompute(img, noArray(), kps, desc)
+// (reference: include/visual_odometry/camera_utility.hpp:746-750).
+//
+// Kernels (all batched over frames, blockIdx.y = frame):
+//   k_colsum + k_integral  : u8 image -> int32 integral image, banded two-level scan
+//   k_hessian_layer        : det/trace of one layer (inspection entry point only)
+//   k_hessian_nms          : fused box-filter Hessian (all 5 layers of an octave into LDS),
+//                            3x3x3 non-max suppression, sub-sample interpolation and
+//                            wavefront-ballot compaction of keypoints; nothing but the
+//                            keypoint list is written to HBM
+//   k_rank + k_scatter     : total-order rank sort (KeypointGreater)
+//   k_describe<>           : orientation + 64-float descriptor, one wavefront per keypoint,
+//                            rotated window sampled row-per-lane straight into the
+//                            INTER_AREA row accumulators held in LDS
+// Arithmetic follows the order of operations of SURVEY.md Appendix A exactly; the file is
+// compiled with -ffp-contract=off so that every float/double operation rounds once.
+#include "vo_common.hpp"
+
+#include <cfloat>
+#include <cmath>
+
+__constant__ DetectTables c_tab;
+
+// ------------------------------------------------------------------------------------------------
+// host: tables
+// ------------------------------------------------------------------------------------------------
+static inline int h_cvRoundF(float v) { return (int)lrintf(v); }
+
+static void gaussian_kernel_f32(int n, double sigma, float* cf) {
+    // cv::getGaussianKernel(n, sigma, CV_32F), non-tabulated branch
+    double scale2X = -0.5 / (sigma * sigma), sum = 0;
+    for (int i = 0; i < n; i++) {
+        double x = i - (n - 1) * 0.5;
+        cf[i] = (float)std::exp(scale2X * x * x);
+        sum += cf[i];
+    }
+    sum = 1. / sum;
+    for (int i = 0; i < n; i++) cf[i] = (float)(cf[i] * sum);
+}
+
+void vo_build_detect_tables(DetectTables& t, int) {
+    std::memset(&t, 0, sizeof(t));
+    for (int o = 0; o < kNumOctaves; o++)
+        for (int l = 0; l < kLayersPerOctave; l++) {
+            LayerTab& L = t.layers[o * kLayersPerOctave + l];
+            L.size = (9 + 6 * l) << o;
+            L.step = 1 << o;
+            L.margin = (L.size / 2) / L.step;
+            float ratio = (float)L.size / 9;
+            auto R = [&](int v) { return h_cvRoundF(ratio * v); };
+            const int ex[4] = {R(0), R(3), R(6), R(9)};
+            const int e27[2] = {R(2), R(7)};
+            const int c[4] = {R(1), R(4), R(5), R(8)};
+            for (int k = 0; k < 4; k++) {
+                L.xdx[k] = ex[k];
+                L.ydy[k] = ex[k];
+                L.cxy[k] = c[k];
+            }
+            for (int k = 0; k < 2; k++) {
+                L.ydx[k] = e27[k];
+                L.xdy[k] = e27[k];
+            }
+            const float wsgn[3] = {1, -2, 1};
+            for (int k = 0; k < 3; k++) {
+                // w = src[4] / ((float)(dx2-dx1) * (dy2-dy1))
+                L.w[k] = wsgn[k] / ((float)(ex[k + 1] - ex[k]) * (e27[1] - e27[0]));
+                L.w[3 + k] = wsgn[k] / ((float)(e27[1] - e27[0]) * (ex[k + 1] - ex[k]));
+            }
+            const int bx[4] = {0, 2, 0, 2}, by[4] = {0, 0, 2, 2};
+            const float ws[4] = {1, -1, -1, 1};
+            for (int k = 0; k < 4; k++)
+                L.w[6 + k] = ws[k] / ((float)(c[bx[k] + 1] - c[bx[k]]) * (c[by[k] + 1] - c[by[k]]));
+        }
+    float G_ori[13];
+    gaussian_kernel_f32(13, 2.5, G_ori);
+    int n = 0;
+    for (int i = -6; i <= 6; i++)
+        for (int j = -6; j <= 6; j++)
+            if (i * i + j * j <= 36) {
+                t.aptx[n] = i;
+                t.apty[n] = j;
+                t.aptw[n++] = G_ori[i + 6] * G_ori[j + 6];
+            }
+    float G_desc[kPatch];
+    gaussian_kernel_f32(kPatch, 3.3, G_desc);
+    for (int i = 0; i < kPatch; i++)
+        for (int j = 0; j < kPatch; j++) t.DW[i * kPatch + j] = G_desc[i] * G_desc[j];
+}
+
+// ------------------------------------------------------------------------------------------------
+// device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int d_cvRoundF(float v) { return __float2int_rn(v); }
+__device__ __forceinline__ int d_cvRoundD(double v) { return __double2int_rn(v); }
+__device__ __forceinline__ int d_cvFloorD(double v) {
+    int i = (int)v;
+    return i - (i > v);
+}
+__device__ __forceinline__ int d_cvCeilD(double v) {
+    int i = (int)v;
+    return i + (i < v);
+}
+
+// cv::fastAtan2 (degrees)
+__device__ __forceinline__ float d_fastAtan2(float y, float x) {
+    const float scale = (float)(180 / 3.1415926535897932384626433832795);
+    const float p1 = 0.9997878412794807f * scale;
+    const float p3 = -0.3258083974640975f * scale;
+    const float p5 = 0.1555786518463281f * scale;
+    const float p7 = -0.04432655554792128f * scale;
+    float ax = fabsf(x), ay = fabsf(y);
+    float a, c, c2;
+    if (ax >= ay) {
+        c = ay / (ax + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    } else {
+        c = ax / (ay + (float)DBL_EPSILON);
+        c2 = c * c;
+        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// Dx, Dy, Dxy of one layer at the sample whose box origin is `org` (pointer into the integral
+// image, row pitch sw).  Integer box sums are exact in any association (mod 2^32); the float
+// multiply and the double accumulation follow calcHaarPattern.
+__device__ __forceinline__ void hessian_boxes(const LayerTab& L, const int32_t* __restrict__ org, int sw, float& dx,
+                                              float& dy, float& dxy) {
+    {
+        const int32_t* r0 = org + L.ydx[0] * sw;
+        const int32_t* r1 = org + L.ydx[1] * sw;
+        uint32_t v0 = (uint32_t)r1[L.xdx[0]] - (uint32_t)r0[L.xdx[0]];
+        uint32_t v1 = (uint32_t)r1[L.xdx[1]] - (uint32_t)r0[L.xdx[1]];
+        uint32_t v2 = (uint32_t)r1[L.xdx[2]] - (uint32_t)r0[L.xdx[2]];
+        uint32_t v3 = (uint32_t)r1[L.xdx[3]] - (uint32_t)r0[L.xdx[3]];
+        double d = (double)((float)(int32_t)(v1 - v0) * L.w[0]);
+        d += (double)((float)(int32_t)(v2 - v1) * L.w[1]);
+        d += (double)((float)(int32_t)(v3 - v2) * L.w[2]);
+        dx = (float)d;
+    }
+    {
+        const int x0 = L.xdy[0], x1 = L.xdy[1];
+        const int32_t* r0 = org + L.ydy[0] * sw;
+        const int32_t* r1 = org + L.ydy[1] * sw;
+        const int32_t* r2 = org + L.ydy[2] * sw;
+        const int32_t* r3 = org + L.ydy[3] * sw;
+        uint32_t h0 = (uint32_t)r0[x1] - (uint32_t)r0[x0];
+        uint32_t h1 = (uint32_t)r1[x1] - (uint32_t)r1[x0];
+        uint32_t h2 = (uint32_t)r2[x1] - (uint32_t)r2[x0];
+        uint32_t h3 = (uint32_t)r3[x1] - (uint32_t)r3[x0];
+        double d = (double)((float)(int32_t)(h1 - h0) * L.w[3]);
+        d += (double)((float)(int32_t)(h2 - h1) * L.w[4]);
+        d += (double)((float)(int32_t)(h3 - h2) * L.w[5]);
+        dy = (float)d;
+    }
+    {
+        const int c0 = L.cxy[0], c1 = L.cxy[1], c2 = L.cxy[2], c3 = L.cxy[3];
+        const int32_t* r0 = org + c0 * sw;
+        const int32_t* r1 = org + c1 * sw;
+        const int32_t* r2 = org + c2 * sw;
+        const int32_t* r3 = org + c3 * sw;
+        // horizontal differences over [c0,c1] and [c2,c3] on the four rows
+        uint32_t a0 = (uint32_t)r0[c1] - (uint32_t)r0[c0], b0 = (uint32_t)r0[c3] - (uint32_t)r0[c2];
+        uint32_t a1 = (uint32_t)r1[c1] - (uint32_t)r1[c0], b1 = (uint32_t)r1[c3] - (uint32_t)r1[c2];
+        uint32_t a2 = (uint32_t)r2[c1] - (uint32_t)r2[c0], b2 = (uint32_t)r2[c3] - (uint32_t)r2[c2];
+        uint32_t a3 = (uint32_t)r3[c1] - (uint32_t)r3[c0], b3 = (uint32_t)r3[c3] - (uint32_t)r3[c2];
+        double d = (double)((float)(int32_t)(a1 - a0) * L.w[6]);  // x[c0,c1] y[c0,c1]
+        d += (double)((float)(int32_t)(b1 - b0) * L.w[7]);        // x[c2,c3] y[c0,c1]
+        d += (double)((float)(int32_t)(a3 - a2) * L.w[8]);        // x[c0,c1] y[c2,c3]
+        d += (double)((float)(int32_t)(b3 - b2) * L.w[9]);        // x[c2,c3] y[c2,c3]
+        dxy = (float)d;
+    }
+}
+
+__device__ __forceinline__ float hessian_det(float dx, float dy, float dxy) {
+    float t1 = dx * dy;
+    float t2 = 0.81f * dxy;
+    float t3 = t2 * dxy;
+    return t1 - t3;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a1: integral image.  Bands of 16 rows; k_colsum gives each band's column sums, k_integral
+// carries them in and scans 16 rows x W with one workgroup per band.
+// ------------------------------------------------------------------------------------------------
+constexpr int kBand = 16;
+
+__global__ __launch_bounds__(256) void k_colsum(const uint8_t* __restrict__ img, size_t img_stride, int H, int W,
+                                                int nbands, int32_t* __restrict__ colsum) {
+    const int frame = blockIdx.z, band = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    const uint8_t* p = img + (size_t)frame * img_stride + (size_t)band * kBand * W + x;
+    const int rows = min(kBand, H - band * kBand);
+    int s = 0;
+    for (int r = 0; r < rows; r++) s += p[(size_t)r * W];
+    colsum[((size_t)frame * nbands + band) * W + x] = s;
+}
+
+template <int CPT>
+__global__ __launch_bounds__(1024) void k_integral(const uint8_t* __restrict__ img, size_t img_stride, int H, int W,
+                                                   int nbands, const int32_t* __restrict__ colsum,
+                                                   int32_t* __restrict__ sum, size_t sum_stride) {
+    __shared__ int32_t s_wtot[kBand][16];
+    const int frame = blockIdx.y, band = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sw = W + 1;
+    const uint8_t* im = img + (size_t)frame * img_stride;
+    int32_t* out = sum + (size_t)frame * sum_stride;
+    const int32_t* cs = colsum + (size_t)frame * nbands * W;
+    const int x0 = tid * CPT;
+    // column sums of all rows above this band
+    int32_t carry[CPT];
+#pragma unroll
+    for (int c = 0; c < CPT; c++) carry[c] = 0;
+    for (int b = 0; b < band; b++) {
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+            if (x0 + c < W) carry[c] += cs[(size_t)b * W + x0 + c];
+    }
+    if (band == 0)
+        for (int x = tid; x < sw; x += 1024) out[x] = 0;
+    int32_t pre[kBand][CPT];  // inclusive prefix over the thread's columns, per row
+    int32_t excl[kBand];      // exclusive prefix of thread totals within the wave
+#pragma unroll
+    for (int r = 0; r < kBand; r++) {
+        const int y = band * kBand + r;
+        int32_t run = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; c++) {
+            if (y < H && x0 + c < W) carry[c] += im[(size_t)y * W + x0 + c];
+            run += (x0 + c < W) ? carry[c] : 0;
+            pre[r][c] = run;
+        }
+        int32_t inc = run;
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            int32_t v = __shfl_up(inc, d, 64);
+            if (lane >= d) inc += v;
+        }
+        excl[r] = inc - run;
+        if (lane == 63) s_wtot[r][wave] = inc;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kBand; r++) {
+        const int y = band * kBand + r;
+        if (y >= H) break;
+        int32_t off = excl[r];
+        for (int w = 0; w < wave; w++) off += s_wtot[r][w];
+        int32_t* row = out + (size_t)(y + 1) * sw;
+        if (tid == 0) row[0] = 0;
+#pragma unroll
+        for (int c = 0; c < CPT; c++)
+            if (x0 + c < W) row[x0 + c + 1] = pre[r][c] + off;
+    }
+}
+
+int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs) {
+    StageScope sc(ctx, ST_INTEGRAL);
+    const int nbands = (fs.H + kBand - 1) / kBand;
+    dim3 g1((fs.W + 255) / 256, nbands, fs.F);
+    hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
+    dim3 g2(nbands, fs.F);
+    const int cpt = (fs.W + 1023) / 1024;
+#define LAUNCH_INT(C)                                                                                              \
+    hipLaunchKernelGGL(k_integral<C>, g2, dim3(1024), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, \
+                       fs.colsum, fs.sum, fs.sum_stride())
+    if (cpt <= 1)
+        LAUNCH_INT(1);
+    else if (cpt <= 2)
+        LAUNCH_INT(2);
+    else if (cpt <= 4)
+        LAUNCH_INT(4);
+    else if (cpt <= 8)
+        LAUNCH_INT(8);
+    else
+        return VO_ERR_UNSUPPORTED;
+#undef LAUNCH_INT
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2 (inspection): one layer's det/trace, materialised.  Border samples are written as 0.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hessian_layer(const int32_t* __restrict__ sum, int H, int W, int layer_idx,
+                                                       float* __restrict__ det, float* __restrict__ trace) {
+    const LayerTab& L = c_tab.layers[layer_idx];
+    const int lrows = H / L.step, lcols = W / L.step;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= lrows || j >= lcols) return;
+    float dv = 0.f, tv = 0.f;
+    if (L.size <= H && L.size <= W) {
+        const int samples_i = 1 + (H - L.size) / L.step, samples_j = 1 + (W - L.size) / L.step;
+        const int oi = i - L.margin, oj = j - L.margin;
+        if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
+            float dx, dy, dxy;
+            hessian_boxes(L, sum + (size_t)(oi * L.step) * (W + 1) + oj * L.step, W + 1, dx, dy, dxy);
+            dv = hessian_det(dx, dy, dxy);
+            tv = dx + dy;
+        }
+    }
+    det[(size_t)i * lcols + j] = dv;
+    trace[(size_t)i * lcols + j] = tv;
+}
+
+int vo_enqueue_hessian_layer(vo_ctx* ctx, FrameSet& fs, int frame, int octave, int layer, float* d_det,
+                             float* d_trace) {
+    const int step = 1 << octave;
+    const int lrows = fs.H / step, lcols = fs.W / step;
+    if (lrows <= 0 || lcols <= 0) return VO_OK;
+    dim3 g((lcols + 63) / 64, (lrows + 3) / 4);
+    hipLaunchKernelGGL(k_hessian_layer, g, dim3(256), 0, ctx->stream, fs.sum + (size_t)frame * fs.sum_stride(), fs.H,
+                       fs.W, octave * kLayersPerOctave + layer, d_det, d_trace);
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// a2 + a3 fused: Hessian of the 5 layers of one octave for a 32x32 sample tile (+1 halo) into
+// LDS, then NMS / interpolation / ballot compaction.  One launch covers all octaves and frames.
+// ------------------------------------------------------------------------------------------------
+constexpr int kTX = 32, kTY = 32, kHX = kTX + 2, kHY = kTY + 2, kHP = kHX + 1;
+
+struct DetectGeom {
+    int H, W;
+    int tiles_x[kNumOctaves], tiles_y[kNumOctaves];
+    int tile_base[kNumOctaves + 1];
+};
+
+// SURFInvoker deletes a keypoint when the gradient wavelet does not fit the integral image or
+// when none of the 109 orientation samples lies inside it; the survivors keep their
+// order, so dropping such keypoints here is equivalent to A.1 step 5.
+__device__ bool kp_describable(float cx, float cy, float size, int H, int W) {
+    const float s = size * 1.2f / 9.0f;
+    const int g = 2 * d_cvRoundF(2 * s);
+    if (H + 1 < g || W + 1 < g) return false;
+    const float half = (float)(g - 1) / 2;
+    for (int kk = 0; kk < kOriSamples; kk++) {
+        int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
+        int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
+        if (!(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g)) return true;
+    }
+    return false;
+}
+
+__global__ __launch_bounds__(256) void k_hessian_nms(const int32_t* __restrict__ sum_base, size_t sum_stride,
+                                                     DetectGeom g, float thr, vo_keypoint* __restrict__ kp_base,
+                                                     int cap, FrameCounters* __restrict__ cnt, int filter_invalid) {
+    __shared__ float s_det[kLayersPerOctave][kHY][kHP];
+    const int frame = blockIdx.y;
+    int b = blockIdx.x, o = 0;
+#pragma unroll
+    for (int q = 1; q < kNumOctaves; q++)
+        if (b >= g.tile_base[q]) o = q;
+    b -= g.tile_base[o];
+    const int ty = b / g.tiles_x[o], tx = b - ty * g.tiles_x[o];
+    const int H = g.H, W = g.W, sw = W + 1;
+    const int step = 1 << o;
+    const int lrows = H / step, lcols = W / step;
+    const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
+    const int tid = threadIdx.x;
+    const int i0 = ty * kTY - 1, j0 = tx * kTX - 1;
+
+    for (int l = 0; l < kLayersPerOctave; l++) {
+        const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
+        const bool fits = (L.size <= H && L.size <= W);
+        const int samples_i = fits ? 1 + (H - L.size) / step : 0;
+        const int samples_j = fits ? 1 + (W - L.size) / step : 0;
+        for (int s = tid; s < kHY * kHX; s += 256) {
+            const int yy = s / kHX, xx = s - yy * kHX;
+            const int oi = i0 + yy - L.margin, oj = j0 + xx - L.margin;
+            float dv = 0.f;
+            if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
+                float dx, dy, dxy;
+                hessian_boxes(L, sum + (size_t)(oi * step) * sw + oj * step, sw, dx, dy, dxy);
+                dv = hessian_det(dx, dy, dxy);
+            }
+            s_det[l][yy][xx] = dv;
+        }
+    }
+    __syncthreads();
+
+    vo_keypoint* __restrict__ kps = kp_base + (size_t)frame * cap;
+    const int lane = tid & 63;
+    for (int l = 1; l <= 3; l++) {
+        const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
+        const int size = L.size;
+        const int size_next = c_tab.layers[o * kLayersPerOctave + l + 1].size;
+        const int size_prev = c_tab.layers[o * kLayersPerOctave + l - 1].size;
+        const int margin = (size_next / 2) / step + 1;
+        for (int s = tid; s < kTY * kTX; s += 256) {
+            const int yy = s >> 5, xx = s & 31;
+            const int i = ty * kTY + yy, j = tx * kTX + xx;
+            bool emit = false;
+            vo_keypoint kpt;
+            if (i >= margin && i < lrows - margin && j >= margin && j < lcols - margin) {
+                const float val0 = s_det[l][yy + 1][xx + 1];
+                if (val0 > thr) {
+                    float N9[3][9];
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int q = 0; q < 9; q++) N9[a][q] = s_det[l - 1 + a][yy + q / 3][xx + q % 3];
+                    bool is_max = true;
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int q = 0; q < 9; q++)
+                            if (!(a == 1 && q == 4)) is_max = is_max && (val0 > N9[a][q]);
+                    if (is_max) {
+                        const int sum_i = step * (i - (size / 2) / step);
+                        const int sum_j = step * (j - (size / 2) / step);
+                        const float center_i = sum_i + (size - 1) * 0.5f;
+                        const float center_j = sum_j + (size - 1) * 0.5f;
+                        // interpolateKeypoint, Cramer's rule in float
+                        const float b0 = -(N9[1][5] - N9[1][3]) / 2;
+                        const float b1 = -(N9[1][7] - N9[1][1]) / 2;
+                        const float b2 = -(N9[2][4] - N9[0][4]) / 2;
+                        const float a00 = N9[1][3] - 2 * N9[1][4] + N9[1][5];
+                        const float a01 = (N9[1][8] - N9[1][6] - N9[1][2] + N9[1][0]) / 4;
+                        const float a02 = (N9[2][5] - N9[2][3] - N9[0][5] + N9[0][3]) / 4;
+                        const float a10 = a01;
+                        const float a11 = N9[1][1] - 2 * N9[1][4] + N9[1][7];
+                        const float a12 = (N9[2][7] - N9[2][1] - N9[0][7] + N9[0][1]) / 4;
+                        const float a20 = a02, a21 = a12;
+                        const float a22 = N9[0][4] - 2 * N9[1][4] + N9[2][4];
+                        float d = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) +
+                                  a02 * (a10 * a21 - a20 * a11);
+                        float x0 = 0, x1 = 0, x2 = 0;
+                        if (d != 0) {
+                            d = 1 / d;
+                            x0 = d * (b0 * (a11 * a22 - a12 * a21) - a01 * (b1 * a22 - a12 * b2) +
+                                      a02 * (b1 * a21 - a11 * b2));
+                            x1 = d * (a00 * (b1 * a22 - a12 * b2) - b0 * (a10 * a22 - a12 * a20) +
+                                      a02 * (a10 * b2 - b1 * a20));
+                            x2 = d * (a00 * (a11 * b2 - b1 * a21) - a01 * (a10 * b2 - b1 * a20) +
+                                      b0 * (a10 * a21 - a11 * a20));
+                        }
+                        const bool ok = (x0 != 0 || x1 != 0 || x2 != 0) && fabsf(x0) <= 1 && fabsf(x1) <= 1 &&
+                                        fabsf(x2) <= 1;
+                        if (ok) {
+                            const int ds = size - size_prev;
+                            kpt.x = center_j + x0 * step;
+                            kpt.y = center_i + x1 * step;
+                            kpt.size = (float)d_cvRoundF((float)size + x2 * ds);
+                            kpt.angle = -1.f;
+                            kpt.response = val0;
+                            kpt.octave = o;
+                            // trace at the same sample (the product path never materialises it)
+                            float dx, dy, dxy;
+                            hessian_boxes(L, sum + (size_t)((i - L.margin) * step) * sw + (j - L.margin) * step, sw,
+                                          dx, dy, dxy);
+                            const float tr = dx + dy;
+                            kpt.class_id = (tr > 0) - (tr < 0);
+                            emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W);
+                        }
+                    }
+                }
+            }
+            // wavefront-ballot compaction: one atomic per wave
+            const unsigned long long m = __ballot(emit);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&cnt[frame].n_raw, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (emit) {
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < cap) kps[pos] = kpt;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// a4: KeypointGreater rank sort.  rank[i] = #{j : kp_j > kp_i}; the order is total, so ranks
+// are a permutation and the scatter is deterministic whatever order NMS appended in.
+// ------------------------------------------------------------------------------------------------
+constexpr int kRankChunk = 1024;
+
+__global__ __launch_bounds__(256) void k_count_clamp(FrameCounters* cnt, int cap, int F) {
+    const int f = blockIdx.x * 256 + threadIdx.x;
+    if (f < F) cnt[f].n_kp = min(cnt[f].n_raw, cap);
+}
+
+__global__ __launch_bounds__(256) void k_rank(const vo_keypoint* __restrict__ kp_base, int cap,
+                                              const FrameCounters* __restrict__ cnt, int* __restrict__ rank_base) {
+    __shared__ float s_r[kRankChunk];
+    const int frame = blockIdx.z;
+    const int n = min(cnt[frame].n_raw, cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int j0 = blockIdx.y * kRankChunk;
+    if (blockIdx.x * 256 >= n || j0 >= n) return;
+    const vo_keypoint* kps = kp_base + (size_t)frame * cap;
+    const int jn = min(kRankChunk, n - j0);
+    for (int q = threadIdx.x; q < jn; q += 256) s_r[q] = kps[j0 + q].response;
+    __syncthreads();
+    if (i >= n) return;
+    const vo_keypoint me = kps[i];
+    int c = 0;
+    for (int q = 0; q < jn; q++) {
+        const float r = s_r[q];
+        c += (r > me.response);
+        if (r == me.response) {  // rare: full KeypointGreater chain
+            const vo_keypoint o = kps[j0 + q];
+            bool gt;
+            if (o.size != me.size)
+                gt = o.size > me.size;
+            else if (o.octave != me.octave)
+                gt = o.octave > me.octave;
+            else if (o.y != me.y)
+                gt = o.y > me.y;
+            else
+                gt = o.x < me.x;
+            c += gt;
+        }
+    }
+    if (c) atomicAdd(&rank_base[(size_t)frame * cap + i], c);
+}
+
+__global__ __launch_bounds__(256) void k_scatter(const vo_keypoint* __restrict__ kp_base, int cap,
+                                                 const FrameCounters* __restrict__ cnt, int* __restrict__ rank_base,
+                                                 vo_keypoint* __restrict__ out_base) {
+    const int frame = blockIdx.y;
+    const int n = min(cnt[frame].n_raw, cap);
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const size_t o = (size_t)frame * cap;
+    const int r = rank_base[o + i];
+    rank_base[o + i] = 0;  // leave the rank array zeroed for the next run
+    if (r < n) out_base[o + r] = kp_base[o + i];
+}
+
+// ------------------------------------------------------------------------------------------------
+// a5 + a6: orientation and descriptor, one wavefront (= one 64-thread workgroup) per keypoint.
+// ------------------------------------------------------------------------------------------------
+constexpr int kSmallWin = 128;  // windows up to 128 px use the 11 KB LDS instance
+constexpr int kBigWin = 768;    // largest window: 21 * 1.2/9 * (216 + 48) = 739
+
+struct CellTab {  // one destination cell of the INTER_AREA decimation table
+    int sx1, sx2;         // full-weight source range [sx1, sx2)
+    int has_head, has_tail;
+    float a_head, a_mid, a_tail;
+    int pad;
+};
+
+__device__ __forceinline__ int sample_pixel(const uint8_t* __restrict__ img, int W, int ncols1, int nrows1, double px,
+                                            double py) {
+    const int ix = d_cvFloorD(px), iy = d_cvFloorD(py);
+    if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
+        const float a = (float)(px - ix), b = (float)(py - iy);
+        const uint8_t* p = img + (size_t)iy * W + ix;
+        const int p00 = p[0], p01 = p[1], p10 = p[W], p11 = p[W + 1];
+        const float oma = 1.f - a, omb = 1.f - b;
+        float v = (float)p00 * oma * omb;
+        v = v + (float)p01 * a * omb;
+        v = v + (float)p10 * oma * b;
+        v = v + (float)p11 * a * b;
+        return (int)(uint8_t)d_cvRoundF(v);
+    }
+    const int x = min(max(d_cvRoundD(px), 0), ncols1);
+    const int y = min(max(d_cvRoundD(py), 0), nrows1);
+    return img[(size_t)y * W + x];
+}
+
+__device__ __forceinline__ int saturate_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+template <int MAXWIN>
+__global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img_base, size_t img_stride,
+                                                 const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+                                                 vo_keypoint* __restrict__ kp_base, float* __restrict__ desc_base,
+                                                 int cap, const FrameCounters* __restrict__ cnt) {
+    __shared__ float s_X[kOriSamples + 3], s_Y[kOriSamples + 3];
+    __shared__ int s_A[kOriSamples + 3];
+    __shared__ CellTab s_cell[kPatch + 1];
+    __shared__ float s_rowbuf[MAXWIN * (kPatch + 1)];  // float or int row accumulators; later DX/DY
+    __shared__ uint8_t s_patch[(kPatch + 1) * (kPatch + 1) + 7];
+    __shared__ float s_vec[64];
+
+    const int frame = blockIdx.y, k = blockIdx.x;
+    const int n = min(cnt[frame].n_raw, cap);
+    if (k >= n) return;
+    vo_keypoint* kpp = kp_base + (size_t)frame * cap + k;
+    const float size = kpp->size;
+    const float cx = kpp->x, cy = kpp->y;
+    const float s = size * 1.2f / 9.0f;
+    const int win = (int)((kPatch + 1) * s);
+    if (MAXWIN == kSmallWin ? (win > kSmallWin) : (win <= kSmallWin)) return;  // handled by the other instance
+    const int lane = threadIdx.x;
+    const int sw = W + 1;
+    const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
+    const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
+
+    // ---------------------------------------------------------------- orientation (A.5)
+    const int g = 2 * d_cvRoundF(2 * s);
+    int nangle = 0;
+    if (!(H + 1 < g || W + 1 < g)) {
+        const int xm = g / 2;  // cvRound((float)g/4 * 2)
+        const float wxa = -1.f / ((float)xm * g), wxb = 1.f / ((float)(g - xm) * g);
+        const float wya = 1.f / ((float)g * xm), wyb = -1.f / ((float)g * (g - xm));
+        const float half = (float)(g - 1) / 2;
+        for (int pass = 0; pass < 2; pass++) {
+            const int kk = pass * 64 + lane;
+            bool inb = false;
+            float X = 0, Y = 0;
+            int Ar = 0;
+            if (kk < kOriSamples) {
+                const int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
+                const int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
+                inb = !(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g);
+                if (inb) {
+                    const int32_t* p = sum + (size_t)y * sw + x;
+                    const uint32_t t00 = p[0], t0m = p[xm], t0g = p[g];
+                    const uint32_t tm0 = p[(size_t)xm * sw], tmg = p[(size_t)xm * sw + g];
+                    const uint32_t tg0 = p[(size_t)g * sw], tgm = p[(size_t)g * sw + xm], tgg = p[(size_t)g * sw + g];
+                    // dx: boxes x[0,xm] (w<0) and x[xm,g] (w>0), both y[0,g]
+                    const int bxa = (int)(t00 + tgm - tg0 - t0m), bxb = (int)(t0m + tgg - tgm - t0g);
+                    double d = (double)((float)bxa * wxa);
+                    d += (double)((float)bxb * wxb);
+                    const float vx = (float)d;
+                    // dy: boxes y[0,xm] (w>0) and y[xm,g] (w<0), both x[0,g]
+                    const int bya = (int)(t00 + tmg - tm0 - t0g), byb = (int)(tm0 + tgg - tg0 - tmg);
+                    d = (double)((float)bya * wya);
+                    d += (double)((float)byb * wyb);
+                    const float vy = (float)d;
+                    const float w = c_tab.aptw[kk];
+                    X = vx * w;
+                    Y = vy * w;
+                    Ar = d_cvRoundF(d_fastAtan2(Y, X));
+                }
+            }
+            const unsigned long long m = __ballot(inb);
+            if (inb) {
+                const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
+                s_X[pos] = X;
+                s_Y[pos] = Y;
+                s_A[pos] = Ar;
+            }
+            nangle += __popcll(m);
+        }
+    }
+    __syncthreads();
+    float descriptor_dir;
+    {
+        float best_mod = 0.f, best_x = 0.f, best_y = 0.f;
+        int best_i = 1 << 30;
+        for (int pass = 0; pass < 2; pass++) {
+            const int wi = pass * 64 + lane;
+            if (wi < 72) {
+                const int i = wi * 5;
+                float sumx = 0, sumy = 0;
+                for (int j = 0; j < nangle; j++) {
+                    const int d = abs(s_A[j] - i);
+                    if (d < 30 || d > 330) {
+                        sumx += s_X[j];
+                        sumy += s_Y[j];
+                    }
+                }
+                const float mod = sumx * sumx + sumy * sumy;
+                if (mod > best_mod) {  // windows visited in increasing i per lane
+                    best_mod = mod;
+                    best_x = sumx;
+                    best_y = sumy;
+                    best_i = i;
+                }
+            }
+        }
+        // first strict maximum over all windows: larger mod wins, ties go to the smaller i
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+            const float om = __shfl_xor(best_mod, d, 64), ox = __shfl_xor(best_x, d, 64),
+                        oy = __shfl_xor(best_y, d, 64);
+            const int oi = __shfl_xor(best_i, d, 64);
+            if (om > best_mod || (om == best_mod && oi < best_i)) {
+                best_mod = om;
+                best_x = ox;
+                best_y = oy;
+                best_i = oi;
+            }
+        }
+        if (!(best_mod > 0.f)) {
+            best_x = 0.f;
+            best_y = 0.f;
+        }
+        descriptor_dir = d_fastAtan2(-best_y, best_x);
+    }
+    if (lane == 0) kpp->angle = descriptor_dir;
+    if (desc_base == nullptr) return;
+
+    // ---------------------------------------------------------------- descriptor (A.6)
+    const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
+    // sin/cos(float) defined as the double function rounded to float (see oracle_surf.cpp)
+    const float sin_dir = -(float)sin((double)dir);
+    const float cos_dir = (float)cos((double)dir);
+    const float win_offset = -(float)(win - 1) / 2;
+    float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
+    float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
+    const int ncols1 = W - 1, nrows1 = H - 1;
+
+    const double scale = (double)win / (kPatch + 1);
+    const int iscale = d_cvRoundD(scale);
+    const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
+    if (!area_fast && lane <= kPatch) {  // computeResizeAreaTab, one destination cell per lane
+        const int dxc = lane;
+        const double fsx1 = dxc * scale, fsx2 = fsx1 + scale;
+        const double cellWidth = fmin(scale, (double)win - fsx1);
+        int sx1 = d_cvCeilD(fsx1), sx2 = d_cvFloorD(fsx2);
+        sx2 = min(sx2, win - 1);
+        sx1 = min(sx1, sx2);
+        CellTab c;
+        c.sx1 = sx1;
+        c.sx2 = sx2;
+        c.has_head = (sx1 - fsx1 > 1e-3);
+        c.a_head = (float)((sx1 - fsx1) / cellWidth);
+        c.a_mid = (float)(1.0 / cellWidth);
+        c.has_tail = (fsx2 - sx2 > 1e-3);
+        c.a_tail = (float)(fmin(fmin(fsx2 - sx2, 1.), cellWidth) / cellWidth);
+        c.pad = 0;
+        s_cell[dxc] = c;
+    }
+    __syncthreads();
+
+    // rows of the window: lane <-> row, columns walked sequentially so that the double
+    // coordinate accumulation (pixel_x += cos_dir) is reproduced step for step.
+    for (int r = 0; r < lane; r++) {
+        start_x += sin_dir;
+        start_y += cos_dir;
+    }
+    int* s_rowint = reinterpret_cast<int*>(s_rowbuf);
+    const double dcos = (double)cos_dir, dsin = (double)sin_dir;
+    for (int base = 0; base < win; base += 64) {
+        const int i = base + lane;
+        if (i < win) {
+            double px = (double)start_x, py = (double)start_y;
+            int cur = 0;
+            int S = sample_pixel(img, W, ncols1, nrows1, px, py);
+            if (area_fast) {
+                for (int dxc = 0; dxc <= kPatch; dxc++) {
+                    int acc = 0;
+                    const int end = (dxc + 1) * iscale;
+                    for (int sx = dxc * iscale; sx < end; sx++) {
+                        while (cur < sx) {
+                            cur++;
+                            px += dcos;
+                            py -= dsin;
+                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
+                        }
+                        acc += S;
+                    }
+                    s_rowint[i * (kPatch + 1) + dxc] = acc;
+                }
+            } else {
+                for (int dxc = 0; dxc <= kPatch; dxc++) {
+                    const CellTab c = s_cell[dxc];
+                    float acc = 0.f;
+                    if (c.has_head) {
+                        const int si = c.sx1 - 1;
+                        while (cur < si) {
+                            cur++;
+                            px += dcos;
+                            py -= dsin;
+                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
+                        }
+                        acc += (float)S * c.a_head;
+                    }
+                    for (int sx = c.sx1; sx < c.sx2; sx++) {
+                        while (cur < sx) {
+                            cur++;
+                            px += dcos;
+                            py -= dsin;
+                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
+                        }
+                        acc += (float)S * c.a_mid;
+                    }
+                    if (c.has_tail) {
+                        const int si = c.sx2;
+                        while (cur < si) {
+                            cur++;
+                            px += dcos;
+                            py -= dsin;
+                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
+                        }
+                        acc += (float)S * c.a_tail;
+                    }
+                    s_rowbuf[i * (kPatch + 1) + dxc] = acc;
+                }
+            }
+        }
+        for (int r = 0; r < 64; r++) {  // this lane's next row is 64 rows further down
+            start_x += sin_dir;
+            start_y += cos_dir;
+        }
+    }
+    __syncthreads();
+
+    // vertical pass of the decimation: one destination pixel per work item
+    for (int it = lane; it < (kPatch + 1) * (kPatch + 1); it += 64) {
+        const int dy = it / (kPatch + 1), dxc = it - dy * (kPatch + 1);
+        int out;
+        if (area_fast) {
+            int tot = 0;
+            for (int sy = dy * iscale; sy < (dy + 1) * iscale; sy++) tot += s_rowint[sy * (kPatch + 1) + dxc];
+            if (iscale == 1)
+                out = tot;
+            else if (iscale == 2)
+                out = (tot + 2) >> 2;
+            else
+                out = saturate_u8(d_cvRoundF((float)tot * (1.f / (float)(iscale * iscale))));
+        } else {
+            const CellTab c = s_cell[dy];
+            float sumv = 0.f;
+            if (c.has_head) sumv += c.a_head * s_rowbuf[(c.sx1 - 1) * (kPatch + 1) + dxc];
+            for (int sy = c.sx1; sy < c.sx2; sy++) sumv += c.a_mid * s_rowbuf[sy * (kPatch + 1) + dxc];
+            if (c.has_tail) sumv += c.a_tail * s_rowbuf[c.sx2 * (kPatch + 1) + dxc];
+            out = saturate_u8(d_cvRoundF(sumv));
+        }
+        s_patch[it] = (uint8_t)out;
+    }
+    __syncthreads();
+
+    // gradients weighted by the Gaussian (DX into s_rowbuf[0..399], DY into [400..799])
+    float* s_DX = s_rowbuf;
+    float* s_DY = s_rowbuf + kPatch * kPatch;
+    for (int it = lane; it < kPatch * kPatch; it += 64) {
+        const int i = it / kPatch, j = it - i * kPatch;
+        const float dw = c_tab.DW[it];
+        const int p00 = s_patch[i * (kPatch + 1) + j], p01 = s_patch[i * (kPatch + 1) + j + 1];
+        const int p10 = s_patch[(i + 1) * (kPatch + 1) + j], p11 = s_patch[(i + 1) * (kPatch + 1) + j + 1];
+        s_DX[it] = (float)(p01 - p00 + p11 - p10) * dw;
+        s_DY[it] = (float)(p10 - p00 + p11 - p01) * dw;
+    }
+    __syncthreads();
+    {
+        // lane = cell*4 + q : 25 sequential float adds per lane, the order of the reference loops
+        const int cell = lane >> 2, q = lane & 3;
+        const int ci = cell >> 2, cj = cell & 3;
+        float acc = 0.f;
+        for (int y = ci * 5; y < ci * 5 + 5; y++)
+            for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                const float tx = s_DX[y * kPatch + x], ty = s_DY[y * kPatch + x];
+                const float v = q == 0 ? tx : (q == 1 ? ty : (q == 2 ? fabsf(tx) : fabsf(ty)));
+                acc += v;
+            }
+        s_vec[lane] = acc;
+    }
+    __syncthreads();
+    double square_mag = 0;
+    for (int kk = 0; kk < 64; kk++) {
+        const float v = s_vec[kk];
+        square_mag += (double)(v * v);
+    }
+    const float nscale = (float)(1. / (sqrt(square_mag) + (double)FLT_EPSILON));
+    desc_base[((size_t)frame * cap + k) * 64 + lane] = s_vec[lane] * nscale;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host: whole detect (+describe) pipeline for a frame set
+// ------------------------------------------------------------------------------------------------
+int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
+    VO_TRY(vo_enqueue_integral(ctx, fs));
+    DetectGeom g;
+    g.H = fs.H;
+    g.W = fs.W;
+    int base = 0;
+    for (int o = 0; o < kNumOctaves; o++) {
+        const int lr = fs.H >> o, lc = fs.W >> o;
+        g.tiles_x[o] = (lc + kTX - 1) / kTX;
+        g.tiles_y[o] = (lr + kTY - 1) / kTY;
+        g.tile_base[o] = base;
+        base += g.tiles_x[o] * g.tiles_y[o];
+    }
+    g.tile_base[kNumOctaves] = base;
+    {
+        StageScope sc(ctx, ST_HESSIAN_NMS);
+        hipLaunchKernelGGL(k_hessian_nms, dim3(base, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(), g,
+                           ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
+        VO_HIP(hipGetLastError());
+    }
+    {
+        StageScope sc(ctx, ST_SORT);
+        hipLaunchKernelGGL(k_count_clamp, dim3((fs.F + 255) / 256), dim3(256), 0, ctx->stream, fs.cnt, fs.cap, fs.F);
+        dim3 gr((fs.cap + 255) / 256, (fs.cap + kRankChunk - 1) / kRankChunk, fs.F);
+        hipLaunchKernelGGL(k_rank, gr, dim3(256), 0, ctx->stream, fs.kp_raw, fs.cap, fs.cnt, fs.rank);
+        hipLaunchKernelGGL(k_scatter, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp_raw, fs.cap,
+                           fs.cnt, fs.rank, fs.kp);
+        VO_HIP(hipGetLastError());
+    }
+    {
+        StageScope sc(ctx, ST_DESCRIBE);
+        float* d = describe ? fs.desc : nullptr;
+        if (describe) {
+            hipLaunchKernelGGL(k_describe<kSmallWin>, dim3(fs.cap, fs.F), dim3(64), 0, ctx->stream, fs.img,
+                               fs.img_stride(), fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cnt);
+            hipLaunchKernelGGL(k_describe<kBigWin>, dim3(fs.cap, fs.F), dim3(64), 0, ctx->stream, fs.img,
+                               fs.img_stride(), fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cnt);
+            VO_HIP(hipGetLastError());
+        }
+    }
+    return VO_OK;
+}
+
+int vo_upload_detect_tables(const DetectTables& t) {
+    VO_HIP(hipMemcpyToSymbol(HIP_SYMBOL(c_tab), &t, sizeof(t)));
+    return VO_OK;
+}
