@@ -30,7 +30,7 @@ void vo_set_hip_error(const char* what, hipError_t e, const char* file, int line
 constexpr int kNumOctaves = 4;
 constexpr int kLayersPerOctave = 5;  // nOctaveLayers + 2
 constexpr int kNumLayers = kNumOctaves * kLayersPerOctave;
-constexpr int kOriSamples = 109;  // grid points with i^2 + j^2 <= 36
+constexpr int kOriSamples = 113;  // lattice points with i^2 + j^2 <= 36 (SURVEY A.5 says 109; the loop it quotes yields 113)
 constexpr int kPatch = 20;        // PATCH_SZ
 constexpr int kMaxHyp = 4096;     // largest max_iters accepted (BASELINE config 5)
 constexpr int kMaxModels = 10;
@@ -47,8 +47,8 @@ struct LayerTab {
 
 struct DetectTables {
     LayerTab layers[kNumLayers];
-    int aptx[kOriSamples + 3], apty[kOriSamples + 3];
-    float aptw[kOriSamples + 3];
+    int aptx[kOriSamples + 15], apty[kOriSamples + 15];
+    float aptw[kOriSamples + 15];
     float DW[kPatch * kPatch];
 };
 

@@ -84,7 +84,7 @@ void vo_build_detect_tables(DetectTables& t, int) {
                 t.aptw[n++] = G_ori[i + 6] * G_ori[j + 6];
             }
     float G_desc[kPatch];
-    gaussian_kernel_f32(kPatch, 3.3, G_desc);
+    gaussian_kernel_f32(kPatch, (double)3.3f, G_desc);  // SURF_DESC_SIGMA is a float constant
     for (int i = 0; i < kPatch; i++)
         for (int j = 0; j < kPatch; j++) t.DW[i * kPatch + j] = G_desc[i] * G_desc[j];
 }
@@ -578,8 +578,8 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
                                                  const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                  vo_keypoint* __restrict__ kp_base, float* __restrict__ desc_base,
                                                  int cap, const FrameCounters* __restrict__ cnt) {
-    __shared__ float s_X[kOriSamples + 3], s_Y[kOriSamples + 3];
-    __shared__ int s_A[kOriSamples + 3];
+    __shared__ float s_X[kOriSamples + 15], s_Y[kOriSamples + 15];
+    __shared__ int s_A[kOriSamples + 15];
     __shared__ CellTab s_cell[kPatch + 1];
     __shared__ float s_rowbuf[MAXWIN * (kPatch + 1)];  // float or int row accumulators; later DX/DY
     __shared__ uint8_t s_patch[(kPatch + 1) * (kPatch + 1) + 7];
