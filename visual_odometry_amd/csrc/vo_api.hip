@@ -312,3 +312,488 @@ extern "C" int vo_detect_describe(vo_ctx* ctx, const uint8_t* img, int rows, int
     }
     return VO_OK;
 }
+
+// ---------------------------------------------------------------- pair buffers
+int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp) {
+    if (ps.P == P && ps.kp_cap == kp_cap && ps.match_cap == match_cap && ps.max_hyp == max_hyp && ps.st) return VO_OK;
+    vo_pairset_free(ps);
+    ps.P = P;
+    ps.kp_cap = kp_cap;
+    ps.match_cap = match_cap;
+    ps.max_hyp = max_hyp;
+    ps.n_split = 8;
+    const size_t pk = (size_t)P * kp_cap, pm = (size_t)P * match_cap, ph = (size_t)P * max_hyp;
+    VO_TRY(dalloc(ps.cand_val, pk * 32));
+    VO_TRY(dalloc(ps.cand_idx, pk * 32));
+    VO_TRY(dalloc(ps.knn_idx, pk * 2));
+    VO_TRY(dalloc(ps.knn_dist, pk * 2));
+    VO_TRY(dalloc(ps.p1, pm * 2));
+    VO_TRY(dalloc(ps.p2, pm * 2));
+    VO_TRY(dalloc(ps.matches, pm));
+    VO_TRY(dalloc(ps.m1, pm * 2));
+    VO_TRY(dalloc(ps.m2, pm * 2));
+    VO_TRY(dalloc(ps.tuples, ph * 5));
+    VO_TRY(dalloc(ps.models, ph * kMaxModels * 9));
+    VO_TRY(dalloc(ps.nmodels, ph));
+    VO_TRY(dalloc(ps.counts, ph * kMaxModels));
+    VO_TRY(dalloc(ps.mask, pm));
+    VO_TRY(dalloc(ps.in1, pm * 2));
+    VO_TRY(dalloc(ps.in2, pm * 2));
+    VO_TRY(dalloc(ps.X4, pm * 4));
+    VO_TRY(dalloc(ps.Xpre, pm * 3));
+    VO_TRY(dalloc(ps.Xk, pm * 3));
+    VO_TRY(dalloc(ps.flag, pm));
+    VO_TRY(dalloc(ps.tmp, pm * 4));
+    VO_TRY(dalloc(ps.st, (size_t)P));
+    VO_HIP(hipMemset(ps.st, 0, (size_t)P * sizeof(PairState)));
+    return VO_OK;
+}
+
+void vo_pairset_free(PairSet& ps) {
+    dfree(ps.cand_val);
+    dfree(ps.cand_idx);
+    dfree(ps.knn_idx);
+    dfree(ps.knn_dist);
+    dfree(ps.p1);
+    dfree(ps.p2);
+    dfree(ps.matches);
+    dfree(ps.m1);
+    dfree(ps.m2);
+    dfree(ps.tuples);
+    dfree(ps.models);
+    dfree(ps.nmodels);
+    dfree(ps.counts);
+    dfree(ps.mask);
+    dfree(ps.in1);
+    dfree(ps.in2);
+    dfree(ps.X4);
+    dfree(ps.Xpre);
+    dfree(ps.Xk);
+    dfree(ps.flag);
+    dfree(ps.tmp);
+    dfree(ps.st);
+    ps.P = ps.kp_cap = ps.match_cap = ps.max_hyp = 0;
+}
+
+static int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+static void init_state(PairState& S, int n, const double* K) {
+    std::memset(&S, 0, sizeof(S));
+    S.n_match = S.n_used = n;
+    S.best_hyp = -1;
+    if (K) std::memcpy(S.K, K, 9 * sizeof(double));
+    S.R[0] = S.R[4] = S.R[8] = 1.0;
+}
+
+// single pair of point lists on the device (P = 1)
+static int stage_points(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, PairState& S, bool as_inliers) {
+    PairSet& ps = ctx->ps;
+    const int mc = round_up(std::max(n, 64), 64);
+    VO_TRY(vo_pairset_alloc(ps, 1, 64, std::max(mc, ps.P == 1 && ps.kp_cap == 64 ? ps.match_cap : 0), kMaxHyp));
+    float* d1 = as_inliers ? ps.in1 : ps.p1;
+    float* d2 = as_inliers ? ps.in2 : ps.p2;
+    if (n > 0) {
+        VO_HIP(hipMemcpyAsync(d1, p1xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        VO_HIP(hipMemcpyAsync(d2, p2xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    }
+    VO_HIP(hipMemcpyAsync(ps.st, &S, sizeof(S), hipMemcpyHostToDevice, ctx->stream));
+    return VO_OK;
+}
+
+static int fetch_state(vo_ctx* ctx, PairSet& ps, int pair, PairState& S) {
+    VO_HIP(hipMemcpyAsync(&S, ps.st + pair, sizeof(S), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- a7
+extern "C" int vo_match_knn2(vo_ctx* ctx, const float* descA, int nA, const float* descB, int nB, int32_t* idx2,
+                             float* dist2) {
+    if (!ctx || !descA || !descB || !idx2 || !dist2 || nA < 0 || nB < 0) return VO_ERR_INVALID_ARG;
+    if (nA == 0) return VO_OK;
+    VO_HIP(hipSetDevice(ctx->device));
+    const int cap = round_up(std::max(std::max(nA, nB), 64), 64);
+    FrameSet& fs = ctx->fs;
+    VO_TRY(vo_frameset_alloc(fs, 2, 16, 16, cap));
+    VO_TRY(vo_pairset_alloc(ctx->ps, 1, cap, 64, kMaxHyp));
+    FrameCounters c[2];
+    std::memset(c, 0, sizeof(c));
+    c[0].n_raw = c[0].n_kp = nA;
+    c[1].n_raw = c[1].n_kp = nB;
+    VO_HIP(hipMemcpyAsync(fs.cnt, c, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(fs.desc, descA, (size_t)nA * 64 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    if (nB > 0)
+        VO_HIP(hipMemcpyAsync(fs.desc + (size_t)cap * 64, descB, (size_t)nB * 64 * sizeof(float), hipMemcpyHostToDevice,
+                              ctx->stream));
+    VO_TRY(vo_enqueue_match(ctx, fs, ctx->ps, false));
+    VO_HIP(hipMemcpyAsync(idx2, ctx->ps.knn_idx, (size_t)nA * 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipMemcpyAsync(dist2, ctx->ps.knn_dist, (size_t)nA * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- opt_DetectFeatures
+extern "C" int vo_detect_match(vo_ctx* ctx, const uint8_t* img1, size_t step1, const uint8_t* img2, size_t step2, int rows,
+                               int cols, float* p1xy, float* p2xy, vo_dmatch* m, int cap, int* n) {
+    if (!ctx || !n || cap < 0) return VO_ERR_INVALID_ARG;
+    *n = 0;
+    VO_TRY(check_image(img1, rows, cols, step1));
+    VO_TRY(check_image(img2, rows, cols, step2));
+    VO_HIP(hipSetDevice(ctx->device));
+    FrameSet& fs = ctx->fs;
+    PairSet& ps = ctx->ps;
+    VO_TRY(vo_frameset_alloc(fs, 2, rows, cols, ctx->prm.kp_capacity));
+    VO_TRY(vo_pairset_alloc(ps, 1, ctx->prm.kp_capacity, round_up(ctx->prm.match_capacity, 64), kMaxHyp));
+    VO_TRY(reset_counters(ctx, fs));
+    VO_TRY(upload_frame(ctx, fs, 0, img1, step1));
+    VO_TRY(upload_frame(ctx, fs, 1, img2, step2));
+    VO_TRY(vo_enqueue_detect(ctx, fs, true));
+    VO_TRY(vo_enqueue_match(ctx, fs, ps, true));
+    PairState S;
+    FrameCounters c[2];
+    VO_HIP(hipMemcpyAsync(c, fs.cnt, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
+    VO_TRY(fetch_state(ctx, ps, 0, S));
+    if (c[0].n_raw > fs.cap || c[1].n_raw > fs.cap) return VO_ERR_CAPACITY;
+    *n = S.n_match;
+    if (S.n_match > ps.match_cap || S.n_match > cap) return VO_ERR_CAPACITY;
+    const size_t k = (size_t)S.n_match;
+    if (k) {
+        if (p1xy) VO_HIP(hipMemcpyAsync(p1xy, ps.p1, k * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (p2xy) VO_HIP(hipMemcpyAsync(p2xy, ps.p2, k * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (m) VO_HIP(hipMemcpyAsync(m, ps.matches, k * sizeof(vo_dmatch), hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- a10
+extern "C" int vo_essential_ransac(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, const double K[9], double prob,
+                                   double thr_px, int max_iters, uint64_t seed, double E[9], uint8_t* mask, int* n_inl,
+                                   int* iters_run) {
+    if (!ctx || !K || !E || !mask || n < 0 || (n > 0 && (!p1xy || !p2xy))) return VO_ERR_INVALID_ARG;
+    if (max_iters < 1 || max_iters > kMaxHyp) return VO_ERR_INVALID_ARG;
+    if (n_inl) *n_inl = 0;
+    if (iters_run) *iters_run = 0;
+    if (n < 5) return VO_ERR_TOO_FEW_POINTS;
+    VO_HIP(hipSetDevice(ctx->device));
+    PairState S;
+    init_state(S, n, K);
+    VO_TRY(stage_points(ctx, p1xy, p2xy, n, S, false));
+    GeoOptions o;
+    o.run_pose = o.run_triang = false;
+    o.prob = prob;
+    o.thr_px = thr_px;
+    o.max_iters = max_iters;
+    o.seed = seed;
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_HIP(hipMemcpyAsync(mask, ctx->ps.mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
+    if (iters_run) *iters_run = S.iters_run;
+    if (S.status != VO_OK) return S.status;
+    std::memcpy(E, S.E, 9 * sizeof(double));
+    if (n_inl) *n_inl = S.n_inl;
+    return VO_OK;
+}
+
+extern "C" int vo_five_point(vo_ctx* ctx, const double* x1, const double* x2, int n_hyp, double* E_out, int32_t* n_models) {
+    if (!ctx || !x1 || !x2 || !E_out || !n_models || n_hyp < 0) return VO_ERR_INVALID_ARG;
+    if (n_hyp == 0) return VO_OK;
+    VO_HIP(hipSetDevice(ctx->device));
+    const size_t pts = (size_t)n_hyp * 10 * sizeof(double), eb = (size_t)n_hyp * 90 * sizeof(double);
+    const size_t tb = (size_t)n_hyp * 5 * sizeof(int), nb = (size_t)n_hyp * sizeof(int);
+    void* tmp = nullptr;
+    VO_TRY(vo_ctx_tmp(ctx, 2 * pts + eb + tb + nb + 64, &tmp));
+    double* d_x1 = (double*)tmp;
+    double* d_x2 = d_x1 + (size_t)n_hyp * 10;
+    double* d_E = d_x2 + (size_t)n_hyp * 10;
+    int* d_t = (int*)(d_E + (size_t)n_hyp * 90);
+    int* d_nm = d_t + (size_t)n_hyp * 5;
+    std::vector<int> tup((size_t)n_hyp * 5);
+    for (size_t i = 0; i < tup.size(); i++) tup[i] = (int)i;
+    VO_HIP(hipMemcpyAsync(d_x1, x1, pts, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(d_x2, x2, pts, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(d_t, tup.data(), tb, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemsetAsync(d_E, 0, eb, ctx->stream));
+    VO_TRY(vo_enqueue_five_point(ctx, d_x1, d_x2, n_hyp, d_t, d_E, d_nm));
+    VO_HIP(hipMemcpyAsync(E_out, d_E, eb, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipMemcpyAsync(n_models, d_nm, nb, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// normalisation kernel lives in vo_geometry.hip (k_geo_prep); here the points go through a PairSet
+extern "C" int vo_sampson_masks(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, const double K[9], double thr_px,
+                                const double* E, int n_models, uint8_t* masks, int32_t* counts) {
+    if (!ctx || !K || !E || !masks || !counts || n < 0 || n_models < 0 || (n > 0 && (!p1xy || !p2xy)))
+        return VO_ERR_INVALID_ARG;
+    for (int k = 0; k < n_models; k++) counts[k] = 0;
+    if (n == 0 || n_models == 0) return VO_OK;
+    VO_HIP(hipSetDevice(ctx->device));
+    PairState S;
+    init_state(S, n, K);
+    VO_TRY(stage_points(ctx, p1xy, p2xy, n, S, false));
+    GeoOptions o;
+    o.run_ransac = o.run_pose = o.run_triang = false;
+    VO_TRY(vo_enqueue_normalise(ctx, ctx->ps, thr_px));
+    void* tmp = nullptr;
+    const size_t eb = (size_t)n_models * 9 * sizeof(double), mb = (size_t)n_models * n, cb = (size_t)n_models * sizeof(int);
+    VO_TRY(vo_ctx_tmp(ctx, eb + cb + mb + 64, &tmp));
+    double* d_E = (double*)tmp;
+    int* d_c = (int*)(d_E + (size_t)n_models * 9);
+    uint8_t* d_m = (uint8_t*)(d_c + n_models);
+    VO_HIP(hipMemcpyAsync(d_E, E, eb, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemsetAsync(d_c, 0, cb, ctx->stream));
+    VO_TRY(vo_enqueue_sampson_masks(ctx, ctx->ps.m1, ctx->ps.m2, n, vo_thr_sq(thr_px, K), d_E, n_models, d_m, d_c));
+    VO_HIP(hipMemcpyAsync(masks, d_m, mb, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipMemcpyAsync(counts, d_c, cb, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- a12
+extern "C" int vo_recover_pose(vo_ctx* ctx, const double E[9], const float* p1xy, const float* p2xy, int n, const double K[9],
+                               double dist_thresh, double R[9], double t[3], int* n_good) {
+    if (!ctx || !E || !K || !R || !t || n <= 0 || !p1xy || !p2xy) return VO_ERR_INVALID_ARG;
+    VO_HIP(hipSetDevice(ctx->device));
+    PairState S;
+    init_state(S, n, K);
+    S.n_inl = n;
+    S.status = VO_OK;
+    std::memcpy(S.E, E, 9 * sizeof(double));
+    VO_TRY(stage_points(ctx, p1xy, p2xy, n, S, true));
+    GeoOptions o;
+    o.run_ransac = o.run_triang = false;
+    o.gate = false;
+    o.dist_thresh = dist_thresh;
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
+    std::memcpy(R, S.R, 9 * sizeof(double));
+    std::memcpy(t, S.t, 3 * sizeof(double));
+    if (n_good) *n_good = S.n_good;
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- optRelativePose
+extern "C" int vo_relative_pose(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, const double K[9], double R_io[9],
+                                double t_io[3], float* in1xy, float* in2xy, int* n_inl, int* success) {
+    if (!ctx || !K || !R_io || !t_io || !n_inl || !success || n < 0 || (n > 0 && (!p1xy || !p2xy))) return VO_ERR_INVALID_ARG;
+    *n_inl = 0;
+    *success = 0;
+    if (n < 5) return VO_ERR_TOO_FEW_POINTS;
+    VO_HIP(hipSetDevice(ctx->device));
+    PairState S;
+    init_state(S, n, K);
+    std::memcpy(S.R, R_io, 9 * sizeof(double));
+    std::memcpy(S.t, t_io, 3 * sizeof(double));
+    VO_TRY(stage_points(ctx, p1xy, p2xy, n, S, false));
+    GeoOptions o;
+    o.run_triang = false;
+    o.prob = ctx->prm.ransac_prob;
+    o.thr_px = ctx->prm.ransac_threshold;
+    o.max_iters = ctx->prm.ransac_max_iters;
+    o.seed = ctx->prm.ransac_seed;
+    o.dist_thresh = ctx->prm.distance_threshold;
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
+    if (S.status != VO_OK) return S.status;
+    *n_inl = S.n_inl;
+    if (S.n_inl > 0) {
+        if (in1xy) VO_HIP(hipMemcpyAsync(in1xy, ctx->ps.in1, (size_t)S.n_inl * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (in2xy) VO_HIP(hipMemcpyAsync(in2xy, ctx->ps.in2, (size_t)S.n_inl * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    *success = S.success;
+    if (S.success) {
+        std::memcpy(R_io, S.R, 9 * sizeof(double));
+        std::memcpy(t_io, S.t, 3 * sizeof(double));
+    }
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- a13 / triangPoints
+extern "C" int vo_triangulate(vo_ctx* ctx, const double P0[12], const double P1[12], const float* p1xy, const float* p2xy, int n,
+                              float* X4) {
+    if (!ctx || !P0 || !P1 || !X4 || n < 0 || (n > 0 && (!p1xy || !p2xy))) return VO_ERR_INVALID_ARG;
+    if (n == 0) return VO_OK;
+    VO_HIP(hipSetDevice(ctx->device));
+    void* tmp = nullptr;
+    const size_t pb = (size_t)n * 2 * sizeof(float), xb = (size_t)n * 4 * sizeof(float);
+    VO_TRY(vo_ctx_tmp(ctx, 24 * sizeof(double) + 2 * pb + xb + 64, &tmp));
+    double* d_P = (double*)tmp;
+    float* d_p1 = (float*)(d_P + 24);
+    float* d_p2 = d_p1 + (size_t)n * 2;
+    float* d_X = d_p2 + (size_t)n * 2;
+    double P01[24];
+    std::memcpy(P01, P0, 12 * sizeof(double));
+    std::memcpy(P01 + 12, P1, 12 * sizeof(double));
+    VO_HIP(hipMemcpyAsync(d_P, P01, sizeof(P01), hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(d_p1, p1xy, pb, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(d_p2, p2xy, pb, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));  // P01 is a stack buffer
+    VO_TRY(vo_enqueue_triangulate(ctx, d_P, d_p1, d_p2, n, d_X));
+    VO_HIP(hipMemcpyAsync(X4, d_X, xb, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
+extern "C" int vo_triang_points(vo_ctx* ctx, const float* in1xy, const float* in2xy, int n, const double R[9], const double t[3],
+                                const double K[9], double* Xk, int cap, int* m) {
+    if (!ctx || !R || !t || !K || !m || n < 0 || cap < 0 || (n > 0 && (!in1xy || !in2xy))) return VO_ERR_INVALID_ARG;
+    *m = 0;
+    if (n == 0) return VO_OK;
+    VO_HIP(hipSetDevice(ctx->device));
+    PairState S;
+    init_state(S, n, K);
+    S.n_inl = n;
+    S.success = 1;
+    std::memcpy(S.R, R, 9 * sizeof(double));
+    std::memcpy(S.t, t, 3 * sizeof(double));
+    VO_TRY(stage_points(ctx, in1xy, in2xy, n, S, true));
+    GeoOptions o;
+    o.run_ransac = o.run_pose = false;
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
+    *m = S.n_world;
+    if (S.n_world > cap) return VO_ERR_CAPACITY;
+    if (S.n_world > 0 && Xk) {
+        for (int r = 0; r < 3; r++)
+            VO_HIP(hipMemcpyAsync(Xk + (size_t)r * cap, ctx->ps.Xk + (size_t)r * ctx->ps.match_cap, (size_t)S.n_world * sizeof(double),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+    }
+    return VO_OK;
+}
+
+// ---------------------------------------------------------------- batch
+extern "C" int vo_batch_create(vo_ctx* ctx, int n_pairs, int rows, int cols, vo_batch** out) {
+    if (!ctx || !out || n_pairs <= 0) return VO_ERR_INVALID_ARG;
+    *out = nullptr;
+    if (rows < 16 || cols < 16 || rows > 8192 || cols > 8192) return VO_ERR_UNSUPPORTED;
+    VO_HIP(hipSetDevice(ctx->device));
+    vo_batch* b = new vo_batch();
+    b->ctx = ctx;
+    b->n_pairs = n_pairs;
+    b->rows = rows;
+    b->cols = cols;
+    int st = vo_frameset_alloc(b->fs, 2 * n_pairs, rows, cols, ctx->prm.kp_capacity);
+    if (st == VO_OK) st = vo_pairset_alloc(b->ps, n_pairs, ctx->prm.kp_capacity, round_up(ctx->prm.match_capacity, 64), kMaxHyp);
+    if (st != VO_OK) {
+        vo_batch_destroy(b);
+        return st;
+    }
+    b->h_state.resize(n_pairs);
+    b->h_cnt.resize(2 * n_pairs);
+    for (auto& S : b->h_state) init_state(S, 0, nullptr);
+    *out = b;
+    return VO_OK;
+}
+
+extern "C" void vo_batch_destroy(vo_batch* b) {
+    if (!b) return;
+    hipSetDevice(b->ctx->device);
+    hipStreamSynchronize(b->ctx->stream);
+    vo_frameset_free(b->fs);
+    vo_pairset_free(b->ps);
+    delete b;
+}
+
+extern "C" int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, size_t step1, const uint8_t* img2, size_t step2,
+                                 const double K[9]) {
+    if (!b || pair < 0 || pair >= b->n_pairs || !K) return VO_ERR_INVALID_ARG;
+    VO_TRY(check_image(img1, b->rows, b->cols, step1));
+    VO_TRY(check_image(img2, b->rows, b->cols, step2));
+    VO_HIP(hipSetDevice(b->ctx->device));
+    VO_TRY(upload_frame(b->ctx, b->fs, 2 * pair, img1, step1));
+    VO_TRY(upload_frame(b->ctx, b->fs, 2 * pair + 1, img2, step2));
+    init_state(b->h_state[pair], 0, K);
+    b->state_dirty = true;
+    return VO_OK;
+}
+
+extern "C" int vo_batch_run(vo_batch* b) {
+    if (!b) return VO_ERR_INVALID_ARG;
+    vo_ctx* ctx = b->ctx;
+    VO_HIP(hipSetDevice(ctx->device));
+    VO_TRY(reset_counters(ctx, b->fs));
+    if (b->state_dirty) {
+        // K / initial pose of every pair; the kernels reset everything else themselves
+        b->h_init = b->h_state;
+        VO_HIP(hipMemcpyAsync(b->ps.st, b->h_init.data(), b->h_init.size() * sizeof(PairState), hipMemcpyHostToDevice, ctx->stream));
+        b->state_dirty = false;
+    }
+    VO_TRY(vo_enqueue_detect(ctx, b->fs, true));
+    VO_TRY(vo_enqueue_match(ctx, b->fs, b->ps, true));
+    GeoOptions o;
+    o.prob = ctx->prm.ransac_prob;
+    o.thr_px = ctx->prm.ransac_threshold;
+    o.max_iters = ctx->prm.ransac_max_iters;
+    o.seed = ctx->prm.ransac_seed;
+    o.dist_thresh = ctx->prm.distance_threshold;
+    VO_TRY(vo_enqueue_geometry(ctx, b->ps, o));
+    b->fetched = false;
+    return VO_OK;
+}
+
+extern "C" int vo_batch_sync(vo_batch* b) {
+    if (!b) return VO_ERR_INVALID_ARG;
+    VO_HIP(hipSetDevice(b->ctx->device));
+    VO_HIP(hipStreamSynchronize(b->ctx->stream));
+    return VO_OK;
+}
+
+static int batch_fetch(vo_batch* b) {
+    if (b->fetched) return VO_OK;
+    vo_ctx* ctx = b->ctx;
+    VO_HIP(hipMemcpyAsync(b->h_state.data(), b->ps.st, b->h_state.size() * sizeof(PairState), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipMemcpyAsync(b->h_cnt.data(), b->fs.cnt, b->h_cnt.size() * sizeof(FrameCounters), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    b->fetched = true;
+    return VO_OK;
+}
+
+extern "C" int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out) {
+    if (!b || !out || pair < 0 || pair >= b->n_pairs) return VO_ERR_INVALID_ARG;
+    VO_HIP(hipSetDevice(b->ctx->device));
+    VO_TRY(batch_fetch(b));
+    const PairState& S = b->h_state[pair];
+    std::memset(out, 0, sizeof(*out));
+    out->n_kp1 = b->h_cnt[2 * pair].n_raw;
+    out->n_kp2 = b->h_cnt[2 * pair + 1].n_raw;
+    out->n_match = S.n_match;
+    out->status = S.status;
+    if (out->n_kp1 > b->fs.cap || out->n_kp2 > b->fs.cap || S.n_match > b->ps.match_cap) out->status = VO_ERR_CAPACITY;
+    out->n_inl = S.n_inl;
+    out->n_good = S.n_good;
+    out->n_world = S.n_world;
+    out->success = S.success;
+    out->iters = S.iters_run;
+    std::memcpy(out->E, S.E, sizeof(out->E));
+    std::memcpy(out->R, S.R, sizeof(out->R));
+    std::memcpy(out->t, S.t, sizeof(out->t));
+    return VO_OK;
+}
+
+extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask, int cap,
+                                   double* Xk, int cap_world) {
+    if (!b || pair < 0 || pair >= b->n_pairs || cap < 0 || cap_world < 0) return VO_ERR_INVALID_ARG;
+    vo_ctx* ctx = b->ctx;
+    VO_HIP(hipSetDevice(ctx->device));
+    VO_TRY(batch_fetch(b));
+    const PairState& S = b->h_state[pair];
+    const PairSet& ps = b->ps;
+    const size_t mc = ps.match_cap;
+    const int nm = std::min(S.n_used, (int)mc);
+    if (nm > cap || S.n_world > cap_world) return VO_ERR_CAPACITY;
+    if (nm > 0) {
+        if (p1xy) VO_HIP(hipMemcpyAsync(p1xy, ps.p1 + pair * mc * 2, (size_t)nm * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (p2xy) VO_HIP(hipMemcpyAsync(p2xy, ps.p2 + pair * mc * 2, (size_t)nm * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        if (m) VO_HIP(hipMemcpyAsync(m, ps.matches + pair * mc, (size_t)nm * sizeof(vo_dmatch), hipMemcpyDeviceToHost, ctx->stream));
+        if (mask) VO_HIP(hipMemcpyAsync(mask, ps.mask + pair * mc, (size_t)nm, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    if (Xk && S.n_world > 0)
+        for (int r = 0; r < 3; r++)
+            VO_HIP(hipMemcpyAsync(Xk + (size_t)r * cap_world, ps.Xk + (pair * 3 + r) * mc, (size_t)S.n_world * sizeof(double),
+                                  hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}

@@ -76,7 +76,8 @@ struct PairState {
     int n_pre;         // triangulated points passing reprojection + Z>0
     int n_world;
     int iters_run;
-    int pad[2];
+    float thr_sq;      // (threshold / f)^2 as float (findInliers)
+    int pad[1];
     double K[9];
     double E[9];
     double R[9];       // in/out pose (identity / zero before the first success)
@@ -148,6 +149,8 @@ struct PairSet {
     float* X4 = nullptr;        // [P][4][match_cap]
     double* Xpre = nullptr;     // [P][match_cap][3] points passing the reprojection filter (frame k)
     double* Xk = nullptr;       // [P][3][match_cap]
+    uint8_t* flag = nullptr;    // [P][match_cap] reprojection filter flags
+    double* tmp = nullptr;      // [P][match_cap*4] scratch of the world-point filter
     PairState* st = nullptr;    // [P]
 };
 
@@ -171,6 +174,9 @@ struct vo_batch {
     int n_pairs = 0, rows = 0, cols = 0;
     FrameSet fs;  // 2 * n_pairs frames: frame 2p = img1 of pair p, 2p+1 = img2
     PairSet ps;
+    std::vector<PairState> h_state, h_init;  // host mirrors (results / initial K and pose)
+    std::vector<FrameCounters> h_cnt;
+    bool state_dirty = true, fetched = false;
 };
 
 // ---------------------------------------------------------------- helpers (vo_api.cpp)
@@ -195,16 +201,22 @@ int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs);
 int vo_enqueue_hessian_layer(vo_ctx* ctx, FrameSet& fs, int frame, int octave, int layer, float* d_det, float* d_trace);
 int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe);
 // vo_match.hip
-int vo_enqueue_match_prep(vo_ctx* ctx, const float* d_desc, size_t desc_stride, const FrameCounters* cnt, int cnt_step,
-                          int cnt_first, int nsets, int cap, float* d_descT, float* d_nrm);
 int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter);
 // vo_geometry.hip
-int vo_enqueue_relative_pose(vo_ctx* ctx, PairSet& ps, bool run_ransac, bool run_pose, bool run_triang);
-int vo_enqueue_five_point(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n_hyp, double* d_E, int* d_nm);
-int vo_enqueue_sampson_masks(vo_ctx* ctx, const double* d_m1, const double* d_m2, int n, double thr_norm,
-                             const double* d_E, int n_models, uint8_t* d_masks, int* d_counts);
-int vo_enqueue_normalise(vo_ctx* ctx, const float* d_p, int n, const double* d_K, double* d_m);
-int vo_enqueue_triangulate(vo_ctx* ctx, const double* d_P0, const double* d_P1, const float* d_p1, const float* d_p2, int n,
-                           float* d_X4);
+struct GeoOptions {
+    bool run_ransac = true, run_pose = true, run_triang = true;
+    bool gate = true;  // optRelativePose gates (inlier ratio, VPF); false = plain recoverPose
+    double prob = 0.99, thr_px = 2.0, dist_thresh = 50.0;
+    int max_iters = 1000;
+    uint64_t seed = (uint64_t)-1;
+};
+int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o);
+int vo_enqueue_five_point(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n_hyp, const int* d_tuples,
+                          double* d_E, int* d_nm);
+int vo_enqueue_sampson_masks(vo_ctx* ctx, const double* d_m1, const double* d_m2, int n, float thr_sq, const double* d_E,
+                             int n_models, uint8_t* d_masks, int* d_counts);
+int vo_enqueue_triangulate(vo_ctx* ctx, const double* d_P01, const float* d_p1, const float* d_p2, int n, float* d_X4);
+float vo_thr_sq(double thr_px, const double K[9]);
+int vo_enqueue_normalise(vo_ctx* ctx, PairSet& ps, double thr_px);
 int vo_upload_detect_tables(const DetectTables& t);
 int vo_geometry_init(vo_ctx* ctx);

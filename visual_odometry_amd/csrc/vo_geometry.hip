@@ -1,0 +1,1465 @@
+// Essential-matrix RANSAC, pose recovery and DLT triangulation for gfx950.
+//
+// Replaces, inside optRelativePose / triangPoints of the reference
+// (include/visual_odometry/camera_utility.hpp:633-685, 288-351):
+//   findEssentialMat(p1,p2,K,RANSAC,0.99,2.0,mask) :642, extract_Inlier :655, recoverPose :667,
+//   triangulatePoints :320, my_convertFromHom :326, reproject_error :330-331, filter_convertWP :348.
+//
+//   k_geo_prep        : pixel -> normalised fp64 coordinates, per-pair state reset
+//   k_ransac_tuples   : the registrator's 5-tuples from the cv::RNG stream (raw 32-bit outputs are
+//                       count-independent and precomputed on the host; modulo, duplicate rejection
+//                       and stream alignment happen here, speculatively 64 tuples at a time)
+//   k_ransac_hyp      : ONE WAVEFRONT PER HYPOTHESIS: null space of the 5x9 system, 10x20
+//                       Gauss-Jordan, degree-10 resultant, Durand-Kerner roots (one lane per root),
+//                       back-substitution (one lane per real root), then Sampson scoring of every
+//                       candidate E against all points (lanes over points, ballot counts)
+//   k_ransac_scan     : in-order scan reproducing the sequential "goodCount > max(best,4)" /
+//                       RANSACUpdateNumIters loop; hypotheses past the live bound exit early
+//   k_ransac_finish   : inlier mask of the winner, ordered inlier compaction, gates
+//   k_pose_decompose / k_pose_cheirality / k_pose_select : recoverPose
+//   k_triang / k_triang_filter : DLT per point, reprojection filter, frame change, 3-sigma filter
+// All arithmetic is fp64 (float only where OpenCV stores float), compiled with -ffp-contract=off.
+#include <cfloat>
+#include <cmath>
+
+#include "vo_common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// small device helpers
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double sum16(double v) {  // sum over an aligned 16-lane group
+    v += __shfl_xor(v, 8, 16);
+    v += __shfl_xor(v, 4, 16);
+    v += __shfl_xor(v, 2, 16);
+    v += __shfl_xor(v, 1, 16);
+    return v;
+}
+
+// One-sided Jacobi SVD of the rows of At (OpenCV JacobiSVDImpl_<double>), N <= 4,
+// fully unrolled so that everything stays in registers.  On return rows of At are normalised left
+// vectors, W the singular values (descending) and rows of V the right vectors.
+template <int N>
+__device__ void jacobi_rows(double (&At)[N][N], double (&W)[N], double (&V)[N][N]) {
+    const double eps = DBL_EPSILON * 10, minval = DBL_MIN;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) sd += At[i][k] * At[i][k];
+        W[i] = sd;
+#pragma unroll
+        for (int k = 0; k < N; k++) V[i][k] = (i == k) ? 1.0 : 0.0;
+    }
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < N - 1; i++)
+#pragma unroll
+            for (int j = i + 1; j < N; j++) {
+                double a = W[i], p = 0, b = W[j];
+#pragma unroll
+                for (int k = 0; k < N; k++) p += At[i][k] * At[j][k];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                const double beta = a - b, gamma = hypot(p, beta);
+                double c, s;
+                if (beta < 0) {
+                    const double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double t0 = c * At[i][k] + s * At[j][k];
+                    const double t1 = -s * At[i][k] + c * At[j][k];
+                    At[i][k] = t0;
+                    At[j][k] = t1;
+                    a += t0 * t0;
+                    b += t1 * t1;
+                }
+                W[i] = a;
+                W[j] = b;
+                changed = true;
+#pragma unroll
+                for (int k = 0; k < N; k++) {
+                    const double t0 = c * V[i][k] + s * V[j][k];
+                    const double t1 = -s * V[i][k] + c * V[j][k];
+                    V[i][k] = t0;
+                    V[j][k] = t1;
+                }
+            }
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) sd += At[i][k] * At[i][k];
+        W[i] = sqrt(sd);
+    }
+    // selection sort, descending (same swaps as the reference loop)
+#pragma unroll
+    for (int i = 0; i < N - 1; i++) {
+        int j = i;
+#pragma unroll
+        for (int k = i + 1; k < N; k++) {
+            double wj = W[i];
+#pragma unroll
+            for (int q = i + 1; q < N; q++)
+                if (q == j) wj = W[q];
+            if (wj < W[k]) j = k;
+        }
+#pragma unroll
+        for (int k = i + 1; k < N; k++)
+            if (k == j) {
+                double tw = W[i];
+                W[i] = W[k];
+                W[k] = tw;
+#pragma unroll
+                for (int q = 0; q < N; q++) {
+                    double t = At[i][q];
+                    At[i][q] = At[k][q];
+                    At[k][q] = t;
+                    t = V[i][q];
+                    V[i][q] = V[k][q];
+                    V[k][q] = t;
+                }
+            }
+    }
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double s = W[i] > minval ? 1 / W[i] : 0.;
+#pragma unroll
+        for (int k = 0; k < N; k++) At[i][k] *= s;
+    }
+}
+
+// cv::triangulatePoints for one point (A.11): X = last row of Vt of the 4x4 system
+__device__ void dlt_point(const double* __restrict__ P0, const double* __restrict__ P1, double x0, double y0, double x1,
+                          double y1, double X[4]) {
+    double At[4][4], W[4], V[4][4];  // At rows = columns of A
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        At[k][0] = x0 * P0[8 + k] - P0[k];
+        At[k][1] = y0 * P0[8 + k] - P0[4 + k];
+        At[k][2] = x1 * P1[8 + k] - P1[k];
+        At[k][3] = y1 * P1[8 + k] - P1[4 + k];
+    }
+    jacobi_rows<4>(At, W, V);
+#pragma unroll
+    for (int k = 0; k < 4; k++) X[k] = V[3][k];
+}
+
+// EMEstimatorCallback::computeError for one point (Sampson distance, stored as float)
+__device__ __forceinline__ float sampson_err(const double E[9], double ax, double ay, double bx, double by) {
+    const double Ex0 = E[0] * ax + E[1] * ay + E[2] * 1.;
+    const double Ex1 = E[3] * ax + E[4] * ay + E[5] * 1.;
+    const double Ex2 = E[6] * ax + E[7] * ay + E[8] * 1.;
+    const double Et0 = E[0] * bx + E[3] * by + E[6] * 1.;
+    const double Et1 = E[1] * bx + E[4] * by + E[7] * 1.;
+    const double x2tEx1 = bx * Ex0 + by * Ex1 + 1. * Ex2;
+    const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+    return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+}
+
+__device__ int d_ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
+    p = fmax(p, 0.);
+    p = fmin(p, 1.);
+    ep = fmax(ep, 0.);
+    ep = fmin(ep, 1.);
+    double num = fmax(1. - p, DBL_MIN);
+    double denom = 1. - pow(1. - ep, (double)modelPoints);
+    if (denom < DBL_MIN) return 0;
+    num = log(num);
+    denom = log(denom);
+    return denom >= 0 || -num >= maxIters * (-denom) ? maxIters : __double2int_rn(num / denom);
+}
+
+// ------------------------------------------------------------------------------------------------
+// preparation
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_geo_prep(const float* __restrict__ p1, const float* __restrict__ p2, int match_cap,
+                                                  double* __restrict__ m1, double* __restrict__ m2,
+                                                  PairState* __restrict__ st, int max_iters, double thr_px, int reset_ransac) {
+    const int pair = blockIdx.y;
+    PairState& S = st[pair];
+    const int n = S.n_used;
+    const double fx = S.K[0], fy = S.K[4], cx = S.K[2], cy = S.K[5];  // skew ignored (A.8)
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < n) {
+        const size_t o = ((size_t)pair * match_cap + i) * 2;
+        m1[o] = ((double)p1[o] - cx) / fx;
+        m1[o + 1] = ((double)p1[o + 1] - cy) / fy;
+        m2[o] = ((double)p2[o] - cx) / fx;
+        m2[o + 1] = ((double)p2[o + 1] - cy) / fy;
+    }
+    if (reset_ransac && blockIdx.x == 0 && threadIdx.x == 0) {
+        const double threshold = thr_px / ((fx + fy) / 2);  // A.8
+        S.thr_sq = (float)(threshold * threshold);
+        S.niters = n < 5 ? 0 : (n == 5 ? 1 : max(max_iters, 1));
+        S.best_count = 0;
+        S.best_hyp = -1;
+        S.best_model = 0;
+        S.scanned = 0;
+        S.n_inl = 0;
+        S.good[0] = S.good[1] = S.good[2] = S.good[3] = 0;
+        S.n_good = 0;
+        S.success = 0;
+        S.status = n < 5 ? VO_ERR_TOO_FEW_POINTS : VO_OK;
+        S.n_pre = 0;
+        S.n_world = 0;
+        S.iters_run = 0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// cv::RNG sample stream -> 5-tuples.  raw[] = successive RNG::next() outputs.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ransac_tuples(const uint32_t* __restrict__ raw, int raw_len,
+                                                      PairState* __restrict__ st, int max_hyp, int* __restrict__ tuples) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    PairState& S = st[pair];
+    const int n = S.n_used;
+    int* out = tuples + (size_t)pair * max_hyp * 5;
+    const int T = min(S.niters, max_hyp);
+    if (n < 5 || T <= 0) return;
+    if (n == 5) {  // count == modelPoints: the kernel runs once on the points as they are
+        if (lane < 5) out[lane] = lane;
+        return;
+    }
+    const unsigned cnt = (unsigned)n;
+    int t = 0, pos = 0;
+    while (t < T) {
+        const int start = pos + 5 * lane;
+        bool dup = false, oob = (start + 5 > raw_len);
+        int d[5] = {0, 0, 0, 0, 0};
+        if (!oob) {
+#pragma unroll
+            for (int q = 0; q < 5; q++) d[q] = (int)(raw[start + q] % cnt);
+            dup = (d[0] == d[1]) || (d[0] == d[2]) || (d[0] == d[3]) || (d[0] == d[4]) || (d[1] == d[2]) ||
+                  (d[1] == d[3]) || (d[1] == d[4]) || (d[2] == d[3]) || (d[2] == d[4]) || (d[3] == d[4]);
+        }
+        const unsigned long long m = __ballot(dup || oob);
+        const int first = m ? (int)__ffsll((long long)m) - 1 : 64;
+        const int adv = min(first, T - t);
+        if (lane < adv) {
+#pragma unroll
+            for (int q = 0; q < 5; q++) out[(size_t)(t + lane) * 5 + q] = d[q];
+        }
+        t += adv;
+        pos += 5 * adv;
+        if (t < T && first < 64) {
+            // the tuple at `pos` rejects at least one draw (or the stream ran out): walk it in order
+            int idx[5] = {0, 0, 0, 0, 0};
+            int i = 0;
+            bool ran_out = false;
+            while (i < 5) {
+                if (pos >= raw_len) {
+                    ran_out = true;
+                    break;
+                }
+                const int v = (int)(raw[pos++] % cnt);
+                bool seen = false;
+#pragma unroll
+                for (int q = 0; q < 5; q++) seen = seen || (q < i && idx[q] == v);
+                if (!seen) {
+#pragma unroll
+                    for (int q = 0; q < 5; q++)
+                        if (q == i) idx[q] = v;
+                    i++;
+                }
+            }
+            if (ran_out) {  // cannot happen with the stream length the host provides; stop cleanly
+                if (lane == 0) S.niters = t;
+                break;
+            }
+            if (lane == 0) {
+#pragma unroll
+                for (int q = 0; q < 5; q++) out[(size_t)t * 5 + q] = idx[q];
+            }
+            t++;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// five-point solver + scoring: one wavefront per hypothesis
+// ------------------------------------------------------------------------------------------------
+// monomial order of the 10x20 system (A.9 step 3)
+//   0:x^3 1:y^3 2:x^2y 3:xy^2 4:x^2z 5:x^2 6:y^2z 7:y^2 8:xyz 9:xy | 10:xz^2 11:xz 12:x 13:yz^2 14:yz 15:y
+//   16:z^3 17:z^2 18:z 19:1
+// linear polys: [x, y, z, 1]; quadratic polys: [x^2, y^2, z^2, xy, xz, yz, x, y, z, 1]
+__device__ __forceinline__ void lin_mul_acc(const double a[4], const double b[4], double out[10], double sgn) {
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            // static table lookups fold at compile time after unrolling
+            const int tbl[4][4] = {{0, 3, 4, 6}, {3, 1, 5, 7}, {4, 5, 2, 8}, {6, 7, 8, 9}};
+            out[tbl[i][j]] += sgn * (a[i] * b[j]);
+        }
+}
+__device__ __forceinline__ void quad_lin_mul_acc(const double a[10], const double b[4], double out[20], double sgn) {
+#pragma unroll
+    for (int i = 0; i < 10; i++)
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int tbl[10][4] = {{0, 2, 4, 5},   {3, 1, 6, 7},   {10, 13, 16, 17}, {2, 3, 8, 9},    {4, 8, 10, 11},
+                                    {8, 6, 13, 14}, {5, 9, 11, 12}, {9, 7, 14, 15},   {11, 14, 17, 18}, {12, 15, 18, 19}};
+            out[tbl[i][j]] += sgn * (a[i] * b[j]);
+        }
+}
+
+struct HypShared {
+    double At[9][9];     // rows 0..4: orthonormal basis of the row space of Q, rows 5..8: null space
+    double Elin[9][4];   // E entry e as a linear polynomial: coefficients of x, y, z, 1
+    double F[9][10];     // 2*E*E^T - tr*I entries (quadratic polynomials)
+    double A[10][20];
+    double fcol[10];
+    double b[3][13];
+    double term[3][11];
+    double c[11];
+    double rre[10], rim[10];
+    double E[kMaxModels][9];
+    double zroot[10];
+    int valid[10];
+    int piv;
+    int nm;
+};
+
+__global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1_base, const double* __restrict__ m2_base,
+                                                   int match_cap, const int* __restrict__ tuples_base, int max_hyp,
+                                                   int h0, int h1, const PairState* __restrict__ st, const int* __restrict__ signs,
+                                                   double* __restrict__ models_base, int* __restrict__ nmodels_base,
+                                                   int* __restrict__ counts_base) {
+    __shared__ HypShared sh;
+    const int pair = blockIdx.y;
+    const int h = h0 + blockIdx.x;
+    const int lane = threadIdx.x;
+    if (h >= h1) return;
+    int n = 0;
+    float thr_sq = 0.f;
+    if (st) {
+        if (h >= st[pair].niters) return;  // past the live RANSAC bound: nothing to do
+        n = st[pair].n_used;
+        thr_sq = st[pair].thr_sq;
+    }
+    const double* __restrict__ m1 = m1_base + (size_t)pair * match_cap * 2;
+    const double* __restrict__ m2 = m2_base + (size_t)pair * match_cap * 2;
+    const int* tup = tuples_base + ((size_t)pair * max_hyp + h) * 5;
+    double* models = models_base + ((size_t)pair * max_hyp + h) * kMaxModels * 9;
+    int* counts = counts_base ? counts_base + ((size_t)pair * max_hyp + h) * kMaxModels : nullptr;
+
+    // ---------------------------------------------------------------- (a) Q (5x9), lanes 0..8 hold column k
+    const int k = lane & 15;  // column index within the 16-lane group; all four groups do the same work
+    double a[9];              // a[i] = At[i][k]
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+        const int id = tup[i];
+        const double x1 = m1[2 * id], y1 = m1[2 * id + 1], x2 = m2[2 * id], y2 = m2[2 * id + 1];
+        // row of Q for vec(E) row-major and x2^T E x1 = 0
+        const double q[9] = {x2 * x1, x2 * y1, x2, y2 * x1, y2 * y1, y2, x1, y1, 1.0};
+        double v = 0;
+#pragma unroll
+        for (int c = 0; c < 9; c++)
+            if (c == k) v = q[c];
+        a[i] = (k < 9) ? v : 0.0;
+    }
+    // ---------------------------------------------------------------- (b) orthonormal row space (MGS, twice)
+#pragma unroll
+    for (int i = 0; i < 5; i++) {
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++)
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                const double d = sum16(a[i] * a[j]);
+                a[i] -= d * a[j];
+            }
+        const double nn = sqrt(sum16(a[i] * a[i]));
+        a[i] *= (nn > DBL_MIN ? 1 / nn : 0.);
+    }
+    // null space: OpenCV's JacobiSVD completes Vt by projecting fixed +-1/9 sign vectors (RNG
+    // 0x12345678) out of the rows found so far; the projector does not depend on the basis chosen
+    // for the row space, so the same four vectors come out here.
+#pragma unroll
+    for (int i = 5; i < 9; i++) {
+        a[i] = (k < 9) ? (signs[(i - 5) * 9 + (k < 9 ? k : 0)] ? 1. / 9 : -1. / 9) : 0.0;
+#pragma unroll
+        for (int rep = 0; rep < 2; rep++)
+#pragma unroll
+            for (int j = 0; j < i; j++) {
+                const double d = sum16(a[i] * a[j]);
+                a[i] -= d * a[j];
+                const double asum = sum16(fabs(a[i]));
+                a[i] *= (asum > DBL_EPSILON * 1000 ? 1 / asum : 0.);
+            }
+        const double nn = sqrt(sum16(a[i] * a[i]));
+        a[i] *= (nn > DBL_MIN ? 1 / nn : 0.);
+    }
+    if (lane < 9) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) sh.At[i][lane] = a[i];
+#pragma unroll
+        for (int v = 0; v < 4; v++) sh.Elin[lane][v] = a[5 + v];  // E = x E1 + y E2 + z E3 + E4
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- (c) constraint polynomials
+    // F = 2 E E^T - tr(E E^T) I  (symmetric, quadratic entries); lanes 0..5 each build one EEt entry
+    if (lane < 6) {
+        const int fi[6] = {0, 0, 0, 1, 1, 2}, fj[6] = {0, 1, 2, 1, 2, 2};
+        int i = 0, j = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+            if (q == lane) {
+                i = fi[q];
+                j = fj[q];
+            }
+        double acc[10];
+#pragma unroll
+        for (int q = 0; q < 10; q++) acc[q] = 0;
+#pragma unroll
+        for (int kk = 0; kk < 3; kk++) {
+            double ea[4], eb[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) {
+                ea[v] = sh.Elin[3 * i + kk][v];
+                eb[v] = sh.Elin[3 * j + kk][v];
+            }
+            lin_mul_acc(ea, eb, acc, 1.0);
+        }
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            sh.F[3 * i + j][q] = acc[q];  // EEt for now
+            sh.F[3 * j + i][q] = acc[q];
+        }
+    }
+    __syncthreads();
+    {
+        // trace and F = 2 EEt - tr I: lanes 0..8 own one entry each
+        double f[10];
+        const int e = lane < 9 ? lane : 0;
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            const double tr = sh.F[0][q] + sh.F[4][q] + sh.F[8][q];
+            f[q] = 2.0 * sh.F[e][q];
+            if (e == 0 || e == 4 || e == 8) f[q] -= tr;
+        }
+        __syncthreads();  // everyone has read EEt before it is overwritten
+        if (lane < 9) {
+#pragma unroll
+            for (int q = 0; q < 10; q++) sh.F[e][q] = f[q];
+        }
+    }
+    __syncthreads();
+    {
+        double row[20];
+#pragma unroll
+        for (int q = 0; q < 20; q++) row[q] = 0;
+        if (lane < 9) {
+            // Lambda_ij = sum_k F_ik E_kj
+            const int i = lane / 3, j = lane - 3 * (lane / 3);
+#pragma unroll
+            for (int kk = 0; kk < 3; kk++) {
+                double f[10], e[4];
+#pragma unroll
+                for (int q = 0; q < 10; q++) f[q] = sh.F[3 * i + kk][q];
+#pragma unroll
+                for (int v = 0; v < 4; v++) e[v] = sh.Elin[3 * kk + j][v];
+                quad_lin_mul_acc(f, e, row, 1.0);
+            }
+        } else if (lane == 9) {
+            // det(E) = E00 (E11 E22 - E12 E21) - E01 (E10 E22 - E12 E20) + E02 (E10 E21 - E11 E20)
+            const int ta[3] = {0, 1, 2};
+            const int m0a[3] = {4, 3, 3}, m0b[3] = {8, 8, 7}, m1a[3] = {5, 5, 4}, m1b[3] = {7, 6, 6};
+            const double sg[3] = {1.0, -1.0, 1.0};
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                double qd[10];
+#pragma unroll
+                for (int q = 0; q < 10; q++) qd[q] = 0;
+                double u[4], v[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u[q] = sh.Elin[m0a[t]][q];
+                    v[q] = sh.Elin[m0b[t]][q];
+                }
+                lin_mul_acc(u, v, qd, 1.0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    u[q] = sh.Elin[m1a[t]][q];
+                    v[q] = sh.Elin[m1b[t]][q];
+                }
+                lin_mul_acc(u, v, qd, -1.0);
+#pragma unroll
+                for (int q = 0; q < 4; q++) u[q] = sh.Elin[ta[t]][q];
+                quad_lin_mul_acc(qd, u, row, sg[t]);
+            }
+        }
+        if (lane < 10) {
+            const int r = lane == 9 ? 0 : lane + 1;  // row 0 = det, rows 1..9 = Lambda (oracle order)
+#pragma unroll
+            for (int q = 0; q < 20; q++) sh.A[r][q] = row[q];
+        }
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- (d) Gauss-Jordan, partial pivoting
+    bool singular = false;
+    for (int col = 0; col < 10; col++) {
+        if (lane == 0) {
+            int piv = col;
+            double best = fabs(sh.A[col][col]);
+            for (int r = col + 1; r < 10; r++) {
+                const double v = fabs(sh.A[r][col]);
+                if (v > best) {
+                    best = v;
+                    piv = r;
+                }
+            }
+            sh.piv = (best == 0) ? -1 : piv;
+        }
+        __syncthreads();
+        const int piv = sh.piv;
+        if (piv < 0) {
+            singular = true;
+            break;
+        }
+        if (lane < 20 && piv != col) {
+            const double t = sh.A[piv][lane];
+            sh.A[piv][lane] = sh.A[col][lane];
+            sh.A[col][lane] = t;
+        }
+        __syncthreads();
+        const double inv = 1.0 / sh.A[col][col];
+        __syncthreads();
+        if (lane < 20) sh.A[col][lane] *= inv;
+        if (lane >= 32 && lane < 42) sh.fcol[lane - 32] = sh.A[lane - 32][col];
+        __syncthreads();
+        for (int e = lane; e < 200; e += 64) {
+            const int r = e / 20, c = e - 20 * r;
+            if (r != col) {
+                const double f = sh.fcol[r];
+                if (f != 0) sh.A[r][c] -= f * sh.A[col][c];
+            }
+        }
+        __syncthreads();
+    }
+    if (singular) {
+        if (lane == 0) nmodels_base[(size_t)pair * max_hyp + h] = 0;
+        return;
+    }
+
+    // ---------------------------------------------------------------- (e) B(z) and its determinant
+    if (lane < 3) {
+        const double* ar1 = &sh.A[4 + 2 * lane][10];
+        const double* ar2 = &sh.A[5 + 2 * lane][10];
+        double row1[13], row2[13];
+#pragma unroll
+        for (int q = 0; q < 13; q++) row1[q] = row2[q] = 0;
+#pragma unroll
+        for (int q = 0; q < 3; q++) {
+            row1[1 + q] = ar1[q];
+            row1[5 + q] = ar1[3 + q];
+            row2[0 + q] = ar2[q];
+            row2[4 + q] = ar2[3 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            row1[9 + q] = ar1[6 + q];
+            row2[8 + q] = ar2[6 + q];
+        }
+#pragma unroll
+        for (int q = 0; q < 13; q++) sh.b[lane][q] = row1[q] - row2[q];
+    }
+    __syncthreads();
+    if (lane < 3) {
+        // term(lane) = sign * f * (g1 h1 - g2 h2), polynomials in ascending powers of z
+        // lane 0: p0 (q1 r2 - q2 r1);  lane 1: -q0 (p1 r2 - p2 r1);  lane 2: r0 (p1 q2 - p2 q1)
+        double P[3][5], Q[3][5], R[3][5];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                P[i][q] = sh.b[i][3 - q];
+                Q[i][q] = sh.b[i][7 - q];
+            }
+            P[i][4] = 0;
+            Q[i][4] = 0;
+#pragma unroll
+            for (int q = 0; q < 5; q++) R[i][q] = sh.b[i][12 - q];
+        }
+        double f[5], g1[5], h1[5], g2[5], h2[5];
+        int df = 3, dg = 3, dh = 4;
+        double sgn = 1.0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            if (lane == 0) {
+                f[q] = P[0][q];
+                g1[q] = Q[1][q];
+                h1[q] = R[2][q];
+                g2[q] = Q[2][q];
+                h2[q] = R[1][q];
+            } else if (lane == 1) {
+                f[q] = Q[0][q];
+                g1[q] = P[1][q];
+                h1[q] = R[2][q];
+                g2[q] = P[2][q];
+                h2[q] = R[1][q];
+            } else {
+                f[q] = R[0][q];
+                g1[q] = P[1][q];
+                h1[q] = Q[2][q];
+                g2[q] = P[2][q];
+                h2[q] = Q[1][q];
+            }
+        }
+        if (lane == 1) sgn = -1.0;
+        if (lane == 2) {
+            df = 4;
+            dh = 3;
+        }
+        double t1[9], t2[9], tt[9], out[13];
+#pragma unroll
+        for (int q = 0; q < 9; q++) t1[q] = t2[q] = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 5; j++) {
+                if (i <= dg && j <= dh) {
+                    t1[i + j] += g1[i] * h1[j];
+                    t2[i + j] += g2[i] * h2[j];
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 9; q++) tt[q] = t1[q] - t2[q];
+#pragma unroll
+        for (int q = 0; q < 13; q++) out[q] = 0;
+#pragma unroll
+        for (int i = 0; i < 5; i++)
+#pragma unroll
+            for (int j = 0; j < 9; j++) {
+                if (i <= df && j <= dg + dh) out[i + j] += f[i] * tt[j];
+            }
+#pragma unroll
+        for (int q = 0; q < 11; q++) sh.term[lane][q] = sgn * out[q];
+    }
+    __syncthreads();
+    if (lane < 11) {
+        double c = 0;
+        c += sh.term[0][lane];
+        c += sh.term[1][lane];
+        c += sh.term[2][lane];
+        sh.c[lane] = c;
+    }
+    __syncthreads();
+
+    // ---------------------------------------------------------------- (f) roots: Durand-Kerner, lane per root
+    int deg = 10;
+    for (; deg > 1; deg--)
+        if (fabs(sh.c[deg]) > DBL_EPSILON) break;
+    {
+        // start values (1+i)^lane as in cv::solvePoly
+        double pr = 1, pi = 0;
+        for (int q = 0; q < lane && q < 10; q++) {
+            const double nr = pr * 1 - pi * 1, ni = pr * 1 + pi * 1;
+            pr = nr;
+            pi = ni;
+        }
+        if (lane < 10) {
+            sh.rre[lane] = pr;
+            sh.rim[lane] = pi;
+        }
+    }
+    __syncthreads();
+    for (int iter = 0; iter < 300; iter++) {
+        double nre = 0, nim = 0, mre = 0, mim = 0;
+        bool moving = false;
+        if (lane < deg) {
+            const double pr = sh.rre[lane], pi = sh.rim[lane];
+            double numr = sh.c[deg], numi = 0, denr = sh.c[deg], deni = 0;
+            for (int j = 0; j < deg; j++) {
+                // num = num*p + c[deg-j-1]
+                const double tr = numr * pr - numi * pi + sh.c[deg - j - 1];
+                const double ti = numr * pi + numi * pr;
+                numr = tr;
+                numi = ti;
+                if (j != lane) {
+                    const double dr = pr - sh.rre[j], di = pi - sh.rim[j];
+                    if (dr != 0 || di != 0) {
+                        const double er = denr * dr - deni * di, ei = denr * di + deni * dr;
+                        denr = er;
+                        deni = ei;
+                    }
+                }
+            }
+            const double t = 1. / (denr * denr + deni * deni);
+            nre = (numr * denr + numi * deni) * t;
+            nim = (-numr * deni + numi * denr) * t;
+            mre = pr - nre;
+            mim = pi - nim;
+            const double mag = fabs(nre) + fabs(nim);
+            moving = mag > 1e-15 * (1.0 + fabs(pr) + fabs(pi));
+        }
+        __syncthreads();
+        if (lane < deg) {
+            sh.rre[lane] = mre;
+            sh.rim[lane] = mim;
+        }
+        const bool any = __ballot(moving) != 0ull;
+        __syncthreads();
+        if (!any) break;
+    }
+
+    // ---------------------------------------------------------------- (g) back-substitution, lane per root
+    bool ok = false;
+    double Ev[9];
+    double z1 = 0;
+    if (lane < deg) {
+        z1 = sh.rre[lane];
+        const double zi = sh.rim[lane];
+        if (!(fabs(zi) > 1e-10)) {
+            const double z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
+            double Bt[3][3], W[3], V[3][3];
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double* br = sh.b[j];
+                // rows of Bt = columns of Bz
+                Bt[0][j] = br[0] * z3 + br[1] * z2 + br[2] * z1 + br[3];
+                Bt[1][j] = br[4] * z3 + br[5] * z2 + br[6] * z1 + br[7];
+                Bt[2][j] = br[8] * z4 + br[9] * z3 + br[10] * z2 + br[11] * z1 + br[12];
+            }
+            jacobi_rows<3>(Bt, W, V);  // SVD::solveZ: last row of Vt
+            if (!(fabs(V[2][2]) < 1e-10)) {
+                const double x = V[2][0] / V[2][2], y = V[2][1] / V[2][2];
+                double nrm = 0;
+#pragma unroll
+                for (int e = 0; e < 9; e++) {
+                    Ev[e] = sh.Elin[e][0] * x + sh.Elin[e][1] * y + sh.Elin[e][2] * z1 + sh.Elin[e][3];
+                    nrm += Ev[e] * Ev[e];
+                }
+                nrm = sqrt(nrm);
+#pragma unroll
+                for (int e = 0; e < 9; e++) Ev[e] = Ev[e] / nrm;
+                ok = true;
+            }
+        }
+    }
+    if (lane < 10) {
+        sh.valid[lane] = ok ? 1 : 0;
+        sh.zroot[lane] = z1;
+    }
+    __syncthreads();
+    int nm = 0, mypos = 0;
+    for (int j = 0; j < 10; j++) {
+        const int vj = sh.valid[j];
+        nm += vj;
+        if (ok && vj && (sh.zroot[j] < z1 || (sh.zroot[j] == z1 && j < lane))) mypos++;
+    }
+    if (ok) {
+#pragma unroll
+        for (int e = 0; e < 9; e++) {
+            sh.E[mypos][e] = Ev[e];
+            models[mypos * 9 + e] = Ev[e];
+        }
+    }
+    if (lane == 0) nmodels_base[(size_t)pair * max_hyp + h] = nm;
+    __syncthreads();
+
+    // ---------------------------------------------------------------- (h) Sampson scoring, lanes over points
+    if (!counts) return;
+    for (int m = 0; m < nm; m++) {
+        double E[9];
+#pragma unroll
+        for (int e = 0; e < 9; e++) E[e] = sh.E[m][e];
+        int cnt = 0;
+        for (int base = 0; base < n; base += 64) {
+            const int i = base + lane;
+            bool in = false;
+            if (i < n) {
+                const double ax = m1[2 * i], ay = m1[2 * i + 1], bx = m2[2 * i], by = m2[2 * i + 1];
+                in = sampson_err(E, ax, ay, bx, by) <= thr_sq;
+            }
+            cnt += __popcll(__ballot(in));
+        }
+        if (lane == 0) counts[m] = cnt;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// sequential-semantics scan over hypotheses [scanned, min(h_end, niters))
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_ransac_scan(PairState* __restrict__ st, int max_hyp, int h_end, double prob,
+                                                    const int* __restrict__ nmodels_base, const int* __restrict__ counts_base) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    PairState& S = st[pair];
+    const int n = S.n_used;
+    if (n < 5) return;
+    const int* nmodels = nmodels_base + (size_t)pair * max_hyp;
+    const int* counts = counts_base + (size_t)pair * max_hyp * kMaxModels;
+    int niters = S.niters, best = S.best_count, best_h = S.best_hyp, best_m = S.best_model;
+    int hcur = S.scanned, mstart = 0;
+    while (hcur < min(h_end, niters)) {
+        const int limit = min(h_end, niters);
+        const int hh = hcur + lane;
+        int found_m = -1, found_c = 0;
+        if (hh < limit) {
+            const int nm = nmodels[hh];
+            const int ms = (lane == 0) ? mstart : 0;
+            const int thr = max(best, 4);
+            for (int m = ms; m < nm; m++) {
+                const int c = counts[hh * kMaxModels + m];
+                if (c > thr) {
+                    found_m = m;
+                    found_c = c;
+                    break;
+                }
+            }
+        }
+        const unsigned long long msk = __ballot(found_m >= 0);
+        if (!msk) {
+            hcur = min(hcur + 64, limit);
+            mstart = 0;
+            continue;
+        }
+        const int fl = (int)__ffsll((long long)msk) - 1;
+        best = __shfl(found_c, fl, 64);
+        best_m = __shfl(found_m, fl, 64);
+        best_h = hcur + fl;
+        niters = d_ransac_update_num_iters(prob, (double)(n - best) / n, 5, niters);
+        hcur = best_h;
+        mstart = best_m + 1;  // later models of the same hypothesis are still compared, in order
+    }
+    if (lane == 0) {
+        S.niters = niters;
+        S.best_count = best;
+        S.best_hyp = best_h;
+        S.best_model = best_m;
+        S.scanned = max(S.scanned, min(h_end, niters));
+        S.iters_run = min(h_end, niters);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// winner -> E, mask, ordered inlier list, "Few Inliers" gate (camera_utility.hpp:644-661)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_ransac_finish(PairState* __restrict__ st, int max_hyp, int match_cap,
+                                                        const double* __restrict__ m1_base, const double* __restrict__ m2_base,
+                                                        const float* __restrict__ p1_base, const float* __restrict__ p2_base,
+                                                        const double* __restrict__ models_base, const int* __restrict__ nmodels_base,
+                                                        uint8_t* __restrict__ mask_base,
+                                                        float* __restrict__ in1_base, float* __restrict__ in2_base) {
+    __shared__ int s_wtot[16];
+    __shared__ int s_base;
+    __shared__ double s_E[9];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PairState& S = st[pair];
+    const int n = S.n_used;
+    const float thr_sq = S.thr_sq;
+    uint8_t* mask = mask_base + (size_t)pair * match_cap;
+    if (n < 5) {
+        for (int i = tid; i < n; i += 1024) mask[i] = 0;
+        return;
+    }
+    int bh = S.best_hyp, bm = S.best_model;
+    bool have = bh >= 0;
+    if (n == 5) {  // count == modelPoints: first model of the single run, mask all ones
+        have = nmodels_base[(size_t)pair * max_hyp] > 0;
+        bh = 0;
+        bm = 0;
+    }
+    if (!have) {
+        for (int i = tid; i < n; i += 1024) mask[i] = 0;
+        if (tid == 0) {
+            S.status = VO_ERR_NO_MODEL;
+            S.n_inl = 0;
+        }
+        return;
+    }
+    if (tid < 9) s_E[tid] = models_base[(((size_t)pair * max_hyp + bh) * kMaxModels + bm) * 9 + tid];
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    double E[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) E[e] = s_E[e];
+    const double* m1 = m1_base + (size_t)pair * match_cap * 2;
+    const double* m2 = m2_base + (size_t)pair * match_cap * 2;
+    const float* p1 = p1_base + (size_t)pair * match_cap * 2;
+    const float* p2 = p2_base + (size_t)pair * match_cap * 2;
+    float* in1 = in1_base + (size_t)pair * match_cap * 2;
+    float* in2 = in2_base + (size_t)pair * match_cap * 2;
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        bool in = false;
+        if (i < n) {
+            in = (n == 5) ? true : (sampson_err(E, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]) <= thr_sq);
+            mask[i] = in ? 1 : 0;
+        }
+        const unsigned long long m = __ballot(in);
+        if (lane == 0) s_wtot[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wtot[w];
+        if (in) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            in1[2 * pos] = p1[2 * i];
+            in1[2 * pos + 1] = p1[2 * i + 1];
+            in2[2 * pos] = p2[2 * i];
+            in2[2 * pos + 1] = p2[2 * i + 1];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wtot[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        S.n_inl = s_base;
+        for (int e = 0; e < 9; e++) S.E[e] = E[e];
+        S.status = VO_OK;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// recoverPose (A.10)
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ double det3(const double m[3][3]) {
+    return m[0][0] * (m[1][1] * m[2][2] - m[1][2] * m[2][1]) - m[0][1] * (m[1][0] * m[2][2] - m[1][2] * m[2][0]) +
+           m[0][2] * (m[1][0] * m[2][1] - m[1][1] * m[2][0]);
+}
+
+// gate = 1: optRelativePose semantics (skip when the inlier ratio is too low); gate = 0: always
+__global__ __launch_bounds__(64) void k_pose_decompose(PairState* __restrict__ st, float inlier_threshold, int gate) {
+    const int pair = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    PairState& S = st[pair];
+    S.good[0] = S.good[1] = S.good[2] = S.good[3] = 0;
+    S.n_good = 0;
+    S.success = 0;
+    if (S.status != VO_OK || S.n_inl <= 0) {
+        S.n_inl = max(S.n_inl, 0);
+        S.niters = -1;  // marks "no pose stage" for the following kernels
+        return;
+    }
+    if (gate && ((float)S.n_inl / (float)S.n_used <= inlier_threshold)) {  // :657 "Few Inliers"
+        S.niters = -1;
+        return;
+    }
+    S.niters = 0;
+    double At[3][3], W[3], V[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) At[i][k] = S.E[3 * k + i];  // rows of At = columns of E
+    jacobi_rows<3>(At, W, V);
+    double U[3][3], Vt[3][3];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int k = 0; k < 3; k++) {
+            U[k][i] = At[i][k];
+            Vt[i][k] = V[i][k];
+        }
+    if (det3(U) < 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) U[i][k] = -U[i][k];
+    }
+    if (det3(Vt) < 0) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int k = 0; k < 3; k++) Vt[i][k] = -Vt[i][k];
+    }
+    const double Wm[3][3] = {{0, 1, 0}, {-1, 0, 0}, {0, 0, 1}}, Wt[3][3] = {{0, -1, 0}, {1, 0, 0}, {0, 0, 1}};
+    double UW[3][3];
+#pragma unroll
+    for (int c = 0; c < 2; c++) {
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                const double(*M)[3] = c == 0 ? Wm : Wt;
+                UW[i][j] = U[i][0] * M[0][j] + U[i][1] * M[1][j] + U[i][2] * M[2][j];
+            }
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 3; j++) S.Rc[c][3 * i + j] = UW[i][0] * Vt[0][j] + UW[i][1] * Vt[1][j] + UW[i][2] * Vt[2][j];
+    }
+    S.tc[0] = U[0][2];
+    S.tc[1] = U[1][2];
+    S.tc[2] = U[2][2];
+}
+
+__global__ __launch_bounds__(256) void k_pose_cheirality(PairState* __restrict__ st, int match_cap,
+                                                         const float* __restrict__ in1_base, const float* __restrict__ in2_base,
+                                                         double dist_thresh) {
+    const int pair = blockIdx.y;
+    PairState& S = st[pair];
+    if (S.niters < 0) return;
+    const int n = S.n_inl;
+    if (blockIdx.x * 256 >= n) return;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const double fx = S.K[0], fy = S.K[4], cx = S.K[2], cy = S.K[5];
+    const float* in1 = in1_base + (size_t)pair * match_cap * 2;
+    const float* in2 = in2_base + (size_t)pair * match_cap * 2;
+    double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
+    if (i < n) {
+        x1 = ((double)in1[2 * i] - cx) / fx;
+        y1 = ((double)in1[2 * i + 1] - cy) / fy;
+        x2 = ((double)in2[2 * i] - cx) / fx;
+        y2 = ((double)in2[2 * i + 1] - cy) / fy;
+    }
+    const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (int c = 0; c < 4; c++) {
+        const double* Rc = S.Rc[(c == 0 || c == 2) ? 0 : 1];
+        const double sgn = c < 2 ? 1.0 : -1.0;
+        double Pk[12];
+#pragma unroll
+        for (int r = 0; r < 3; r++) {
+#pragma unroll
+            for (int q = 0; q < 3; q++) Pk[4 * r + q] = Rc[3 * r + q];
+            Pk[4 * r + 3] = sgn * S.tc[r];
+        }
+        bool good = false;
+        if (i < n) {
+            double Q[4];
+            dlt_point(P0, Pk, x1, y1, x2, y2, Q);
+            bool m = (Q[2] * Q[3] > 0);
+            const double q0 = Q[0] / Q[3], q1 = Q[1] / Q[3], q2 = Q[2] / Q[3], q3 = Q[3] / Q[3];
+            m = m && (q2 < dist_thresh);
+            const double z = Pk[8] * q0 + Pk[9] * q1 + Pk[10] * q2 + Pk[11] * q3;
+            m = m && (z > 0) && (z < dist_thresh);
+            good = m;
+        }
+        const unsigned long long b = __ballot(good);
+        if (lane == 0 && b) atomicAdd(&S.good[c], __popcll(b));
+    }
+}
+
+// gate = 1: R/t of the state are overwritten only when VPF >= threshold (optRelativePose);
+// gate = 0: plain recoverPose
+__global__ __launch_bounds__(64) void k_pose_select(PairState* __restrict__ st, float vpf_threshold, int gate) {
+    const int pair = blockIdx.x;
+    if (threadIdx.x != 0) return;
+    PairState& S = st[pair];
+    if (S.niters < 0) return;
+    const int g0 = S.good[0], g1 = S.good[1], g2 = S.good[2], g3 = S.good[3];
+    int sel;
+    if (g0 >= g1 && g0 >= g2 && g0 >= g3)
+        sel = 0;
+    else if (g1 >= g0 && g1 >= g2 && g1 >= g3)
+        sel = 1;
+    else if (g2 >= g0 && g2 >= g1 && g2 >= g3)
+        sel = 2;
+    else
+        sel = 3;
+    S.n_good = S.good[sel];
+    const float vpf = (float)S.n_good / (float)S.n_inl;  // :669
+    if (!gate || vpf >= vpf_threshold) {
+        const double* Rs = S.Rc[(sel == 0 || sel == 2) ? 0 : 1];
+        const double sg = sel < 2 ? 1.0 : -1.0;
+        for (int q = 0; q < 9; q++) S.R[q] = Rs[q];
+        for (int q = 0; q < 3; q++) S.t[q] = sg * S.tc[q];
+        S.success = 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// triangulation (A.11, A.12)
+// ------------------------------------------------------------------------------------------------
+// mode 0: raw triangulatePoints with given P0/P1 (X4 only); mode 1: triangPoints of the reference
+__global__ __launch_bounds__(256) void k_triang(PairState* __restrict__ st, int match_cap, const float* __restrict__ in1_base,
+                                                const float* __restrict__ in2_base, const double* __restrict__ Pext,
+                                                int n_ext, int need_success, float reproj_tol,
+                                                float* __restrict__ X4_base, double* __restrict__ Xpre_base,
+                                                uint8_t* __restrict__ flag_base) {
+    const int pair = blockIdx.y;
+    int n;
+    double P0[12], P1[12], R[9], t[3], K[9];
+    if (Pext) {
+        n = n_ext;
+#pragma unroll
+        for (int q = 0; q < 12; q++) {
+            P0[q] = Pext[q];
+            P1[q] = Pext[12 + q];
+        }
+    } else {
+        PairState& S = st[pair];
+        if (need_success && !S.success) return;
+        n = S.n_inl;
+#pragma unroll
+        for (int q = 0; q < 9; q++) {
+            R[q] = S.R[q];
+            K[q] = S.K[q];
+        }
+#pragma unroll
+        for (int q = 0; q < 3; q++) t[q] = S.t[q];
+        // projectionMatrix(): K * [R|t], K * [I|0]  (camera_utility.hpp:280-286, 316-317)
+#pragma unroll
+        for (int i = 0; i < 3; i++)
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+                double s0 = 0, s1 = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    s0 += K[3 * i + k] * ((j < 3) ? (k == j ? 1.0 : 0.0) : 0.0);
+                    s1 += K[3 * i + k] * ((j < 3) ? R[3 * k + j] : t[k]);
+                }
+                P0[4 * i + j] = s0;
+                P1[4 * i + j] = s1;
+            }
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float* in1 = in1_base + (size_t)pair * match_cap * 2;
+    const float* in2 = in2_base + (size_t)pair * match_cap * 2;
+    const float u1 = in1[2 * i], v1 = in1[2 * i + 1], u2 = in2[2 * i], v2 = in2[2 * i + 1];
+    double X[4];
+    dlt_point(P0, P1, (double)u1, (double)v1, (double)u2, (double)v2, X);
+    float h[4];
+    float* X4 = X4_base + (size_t)pair * 4 * match_cap;
+    const int ld = Pext ? n_ext : match_cap;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        h[q] = (float)X[q];
+        X4[(size_t)q * ld + i] = h[q];
+    }
+    if (Pext) return;
+    // my_convertFromHom (float divide, :544) -> CV_64F (:327)
+    const double Xw[3] = {(double)(h[0] / h[3]), (double)(h[1] / h[3]), (double)(h[2] / h[3])};
+    const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
+    double e[2];
+#pragma unroll
+    for (int view = 0; view < 2; view++) {
+        double x, y, z;
+        if (view == 0) {
+            x = 1.0 * Xw[0] + 0.0 * Xw[1] + 0.0 * Xw[2] + 0.0;
+            y = 0.0 * Xw[0] + 1.0 * Xw[1] + 0.0 * Xw[2] + 0.0;
+            z = 0.0 * Xw[0] + 0.0 * Xw[1] + 1.0 * Xw[2] + 0.0;
+        } else {
+            x = R[0] * Xw[0] + R[1] * Xw[1] + R[2] * Xw[2] + t[0];
+            y = R[3] * Xw[0] + R[4] * Xw[1] + R[5] * Xw[2] + t[1];
+            z = R[6] * Xw[0] + R[7] * Xw[1] + R[8] * Xw[2] + t[2];
+        }
+        z = z ? 1. / z : 1;
+        x *= z;
+        y *= z;
+        const double u = x * fx + cx, v = y * fy + cy;
+        const double du = (double)(view == 0 ? u1 : u2) - u, dv = (double)(view == 0 ? v1 : v2) - v;
+        e[view] = sqrt(du * du + dv * dv);
+    }
+    const double mean = (e[0] + e[1]) / 2.0;
+    const bool keep = (mean < (double)reproj_tol) && (Xw[2] > 0);  // filter_convertWP :559
+    flag_base[(size_t)pair * match_cap + i] = keep ? 1 : 0;
+    double* Xp = Xpre_base + ((size_t)pair * match_cap + i) * 3;
+#pragma unroll
+    for (int r = 0; r < 3; r++) Xp[r] = R[3 * r] * Xw[0] + R[3 * r + 1] * Xw[1] + R[3 * r + 2] * Xw[2] + t[r];  // coordTransf
+}
+
+// ordered compaction of the kept points, var_avgMat (sequential sums, math_utility.hpp:235-258),
+// 3-sigma filter on Z (:575-583); output Xk is [3][match_cap]
+__global__ __launch_bounds__(1024) void k_triang_filter(PairState* __restrict__ st, int match_cap,
+                                                        const uint8_t* __restrict__ flag_base, const double* __restrict__ Xpre_base,
+                                                        double* __restrict__ tmp_base, double* __restrict__ Xk_base) {
+    __shared__ int s_wtot[16];
+    __shared__ int s_base;
+    __shared__ double s_stat[2];
+    const int pair = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    PairState& S = st[pair];
+    if (!S.success) {
+        if (tid == 0) {
+            S.n_pre = 0;
+            S.n_world = 0;
+        }
+        return;
+    }
+    const int n = S.n_inl;
+    const uint8_t* flag = flag_base + (size_t)pair * match_cap;
+    const double* Xpre = Xpre_base + (size_t)pair * match_cap * 3;
+    double* good = tmp_base + (size_t)pair * match_cap * 4;  // [M][3] compacted, then [M] scratch
+    double* scr = good + (size_t)match_cap * 3;
+    double* Xk = Xk_base + (size_t)pair * 3 * match_cap;
+    if (tid == 0) s_base = 0;
+    __syncthreads();
+    for (int base = 0; base < n; base += 1024) {
+        const int i = base + tid;
+        const bool keep = (i < n) && flag[i];
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wtot[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wtot[w];
+        if (keep) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            good[3 * pos] = Xpre[3 * i];
+            good[3 * pos + 1] = Xpre[3 * i + 1];
+            good[3 * pos + 2] = Xpre[3 * i + 2];
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wtot[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    const int M = s_base;
+    if (M == 0) {
+        if (tid == 0) {
+            S.n_pre = 0;
+            S.n_world = 0;
+        }
+        return;
+    }
+    __threadfence_block();
+    __syncthreads();
+    // mean: the divisions run in parallel, the additions in the reference's order
+    for (int i = tid; i < M; i += 1024) scr[i] = good[3 * i + 2] / M;
+    __syncthreads();
+    if (tid == 0) {
+        double mean = 0;
+        for (int i = 0; i < M; i++) mean += scr[i];
+        s_stat[0] = mean;
+    }
+    __syncthreads();
+    const double mean = s_stat[0];
+    for (int i = tid; i < M; i += 1024) {
+        const double d = good[3 * i + 2] - mean;
+        scr[i] = d * d / M;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double var = 0;
+        for (int i = 0; i < M; i++) var += scr[i];
+        s_stat[1] = var;
+        s_base = 0;
+    }
+    __syncthreads();
+    const double sd3 = 3.0 * sqrt(s_stat[1]);
+    const double hi = mean + sd3, lo = mean - sd3;
+    for (int base = 0; base < M; base += 1024) {
+        const int i = base + tid;
+        bool keep = false;
+        double z = 0;
+        if (i < M) {
+            z = good[3 * i + 2];
+            keep = (z <= hi) && (z >= lo);
+        }
+        const unsigned long long m = __ballot(keep);
+        if (lane == 0) s_wtot[wave] = __popcll(m);
+        __syncthreads();
+        int off = s_base;
+        for (int w = 0; w < wave; w++) off += s_wtot[w];
+        if (keep) {
+            const int pos = off + __popcll(m & ((1ull << lane) - 1ull));
+            Xk[pos] = good[3 * i];
+            Xk[(size_t)match_cap + pos] = good[3 * i + 1];
+            Xk[(size_t)2 * match_cap + pos] = z;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            int tot = 0;
+            for (int w = 0; w < 16; w++) tot += s_wtot[w];
+            s_base += tot;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        S.n_pre = M;
+        S.n_world = s_base;
+        S.zstat[0] = mean;
+        S.zstat[1] = s_stat[1];
+    }
+}
+
+// masks + counts of explicit models (inspection entry point vo_sampson_masks)
+__global__ __launch_bounds__(256) void k_sampson_masks(const double* __restrict__ m1, const double* __restrict__ m2, int n,
+                                                       const double* __restrict__ Es, float thr_sq,
+                                                       uint8_t* __restrict__ masks, int* __restrict__ counts) {
+    const int model = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    double E[9];
+#pragma unroll
+    for (int e = 0; e < 9; e++) E[e] = Es[9 * model + e];
+    bool in = false;
+    if (i < n) {
+        in = sampson_err(E, m1[2 * i], m1[2 * i + 1], m2[2 * i], m2[2 * i + 1]) <= thr_sq;
+        masks[(size_t)model * n + i] = in ? 1 : 0;
+    }
+    const unsigned long long b = __ballot(in);
+    if ((threadIdx.x & 63) == 0 && b) atomicAdd(&counts[model], __popcll(b));
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+struct GeoGlobals {
+    int* d_signs = nullptr;       // 36 sign bits of JacobiSVD's completion vectors
+    uint32_t* d_raw = nullptr;    // cv::RNG stream
+    int raw_len = 0;
+    uint64_t raw_seed = 0;
+    bool have_raw = false;
+};
+static GeoGlobals g_geo[16];
+
+static inline uint32_t rng_next(uint64_t& state) {
+    state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
+    return (uint32_t)state;
+}
+
+int vo_geometry_init(vo_ctx* ctx) {
+    GeoGlobals& G = g_geo[ctx->device & 15];
+    if (!G.d_signs) {
+        int signs[36];
+        uint64_t s = 0x12345678;
+        for (int i = 0; i < 36; i++) signs[i] = (rng_next(s) & 256) != 0 ? 1 : 0;
+        VO_HIP(hipMalloc((void**)&G.d_signs, sizeof(signs)));
+        VO_HIP(hipMemcpy(G.d_signs, signs, sizeof(signs), hipMemcpyHostToDevice));
+    }
+    if (!G.d_raw) {
+        G.raw_len = kMaxHyp * 16 + 4096;
+        VO_HIP(hipMalloc((void**)&G.d_raw, (size_t)G.raw_len * sizeof(uint32_t)));
+    }
+    return VO_OK;
+}
+
+static int ensure_raw(vo_ctx* ctx, uint64_t seed) {
+    GeoGlobals& G = g_geo[ctx->device & 15];
+    if (G.have_raw && G.raw_seed == seed) return VO_OK;
+    std::vector<uint32_t> raw(G.raw_len);
+    uint64_t s = seed ? seed : 0xffffffffULL;  // cv::RNG(0) falls back to 0xffffffff
+    for (int i = 0; i < G.raw_len; i++) raw[i] = rng_next(s);
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    VO_HIP(hipMemcpy(G.d_raw, raw.data(), raw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    G.raw_seed = seed;
+    G.have_raw = true;
+    return VO_OK;
+}
+
+extern "C" int vo_ransac_subsets(uint64_t seed, int count, int n_tuples, int32_t* idx5) {
+    if (!idx5 || count < 5 || n_tuples < 0) return VO_ERR_INVALID_ARG;
+    uint64_t s = seed ? seed : 0xffffffffULL;
+    for (int t = 0; t < n_tuples; t++) {
+        int32_t* idx = idx5 + 5 * (size_t)t;
+        for (int i = 0; i < 5;) {
+            const int v = (int)(rng_next(s) % (unsigned)count);
+            bool seen = false;
+            for (int q = 0; q < i; q++) seen = seen || idx[q] == v;
+            if (!seen) idx[i++] = v;
+        }
+    }
+    return VO_OK;
+}
+
+static float thr_sq_of(double thr_px, const double K[9]) {
+    const double threshold = thr_px / ((K[0] + K[4]) / 2);
+    return (float)(threshold * threshold);
+}
+
+// RANSAC (optional) -> pose (optional) -> triangPoints (optional) for every pair of the set.
+// The K used for the threshold is the same for all pairs of a set when called from the batch API
+// with differing intrinsics the threshold is taken per pair on the device.
+int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o) {
+    GeoGlobals& G = g_geo[ctx->device & 15];
+    const int P = ps.P, mc = ps.match_cap;
+    if (o.run_ransac) {
+        VO_TRY(ensure_raw(ctx, o.seed));
+        {
+            StageScope sc(ctx, ST_RANSAC_SAMPLE);
+            hipLaunchKernelGGL(k_geo_prep, dim3((mc + 255) / 256, P), dim3(256), 0, ctx->stream, ps.p1, ps.p2, mc, ps.m1,
+                               ps.m2, ps.st, o.max_iters, o.thr_px, 1);
+            hipLaunchKernelGGL(k_ransac_tuples, dim3(P), dim3(64), 0, ctx->stream, G.d_raw, G.raw_len, ps.st, ps.max_hyp,
+                               ps.tuples);
+            VO_HIP(hipGetLastError());
+        }
+        const int bounds[6] = {0, 64, 256, 1024, 2048, 4096};
+        for (int c = 0; c < 5; c++) {
+            const int h0 = bounds[c], h1 = std::min(bounds[c + 1], o.max_iters);
+            if (h0 >= h1) break;
+            {
+                StageScope sc(ctx, ST_RANSAC_SOLVE_SCORE);
+                hipLaunchKernelGGL(k_ransac_hyp, dim3(h1 - h0, P), dim3(64), 0, ctx->stream, ps.m1, ps.m2, mc, ps.tuples,
+                                   ps.max_hyp, h0, h1, ps.st, G.d_signs, ps.models,
+                                   ps.nmodels, ps.counts);
+                VO_HIP(hipGetLastError());
+            }
+            {
+                StageScope sc(ctx, ST_RANSAC_SELECT);
+                hipLaunchKernelGGL(k_ransac_scan, dim3(P), dim3(64), 0, ctx->stream, ps.st, ps.max_hyp, h1, o.prob,
+                                   ps.nmodels, ps.counts);
+                VO_HIP(hipGetLastError());
+            }
+        }
+        {
+            StageScope sc(ctx, ST_RANSAC_SELECT);
+            hipLaunchKernelGGL(k_ransac_finish, dim3(P), dim3(1024), 0, ctx->stream, ps.st, ps.max_hyp, mc, ps.m1, ps.m2,
+                               ps.p1, ps.p2, ps.models, ps.nmodels, ps.mask, ps.in1, ps.in2);
+            VO_HIP(hipGetLastError());
+        }
+    }
+    if (o.run_pose) {
+        StageScope sc(ctx, ST_POSE);
+        hipLaunchKernelGGL(k_pose_decompose, dim3(P), dim3(64), 0, ctx->stream, ps.st, ctx->prm.inlier_threshold,
+                           o.gate ? 1 : 0);
+        hipLaunchKernelGGL(k_pose_cheirality, dim3((mc + 255) / 256, P), dim3(256), 0, ctx->stream, ps.st, mc, ps.in1,
+                           ps.in2, o.dist_thresh);
+        hipLaunchKernelGGL(k_pose_select, dim3(P), dim3(64), 0, ctx->stream, ps.st, ctx->prm.vpf_threshold, o.gate ? 1 : 0);
+        VO_HIP(hipGetLastError());
+    }
+    if (o.run_triang) {
+        StageScope sc(ctx, ST_TRIANGULATE);
+        hipLaunchKernelGGL(k_triang, dim3((mc + 255) / 256, P), dim3(256), 0, ctx->stream, ps.st, mc, ps.in1, ps.in2,
+                           (const double*)nullptr, 0, 1, ctx->prm.reprojection_tolerance, ps.X4, ps.Xpre, ps.flag);
+        hipLaunchKernelGGL(k_triang_filter, dim3(P), dim3(1024), 0, ctx->stream, ps.st, mc, ps.flag, ps.Xpre, ps.tmp,
+                           ps.Xk);
+        VO_HIP(hipGetLastError());
+    }
+    return VO_OK;
+}
+
+int vo_enqueue_five_point(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n_hyp, const int* d_tuples,
+                          double* d_E, int* d_nm) {
+    GeoGlobals& G = g_geo[ctx->device & 15];
+    StageScope sc(ctx, ST_RANSAC_SOLVE_SCORE);
+    hipLaunchKernelGGL(k_ransac_hyp, dim3(n_hyp, 1), dim3(64), 0, ctx->stream, d_x1, d_x2, 0, d_tuples, n_hyp, 0, n_hyp,
+                       (const PairState*)nullptr, G.d_signs, d_E, d_nm, (int*)nullptr);
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_enqueue_sampson_masks(vo_ctx* ctx, const double* d_m1, const double* d_m2, int n, float thr_sq, const double* d_E,
+                             int n_models, uint8_t* d_masks, int* d_counts) {
+    if (n <= 0 || n_models <= 0) return VO_OK;
+    hipLaunchKernelGGL(k_sampson_masks, dim3((n + 255) / 256, n_models), dim3(256), 0, ctx->stream, d_m1, d_m2, n, d_E,
+                       thr_sq, d_masks, d_counts);
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+int vo_enqueue_triangulate(vo_ctx* ctx, const double* d_P01, const float* d_p1, const float* d_p2, int n, float* d_X4) {
+    if (n <= 0) return VO_OK;
+    StageScope sc(ctx, ST_TRIANGULATE);
+    hipLaunchKernelGGL(k_triang, dim3((n + 255) / 256, 1), dim3(256), 0, ctx->stream, (PairState*)nullptr, 0, d_p1, d_p2,
+                       d_P01, n, 0, 0.f, d_X4, (double*)nullptr, (uint8_t*)nullptr);
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+float vo_thr_sq(double thr_px, const double K[9]) { return thr_sq_of(thr_px, K); }
+
+int vo_enqueue_normalise(vo_ctx* ctx, PairSet& ps, double thr_px) {
+    hipLaunchKernelGGL(k_geo_prep, dim3((ps.match_cap + 255) / 256, ps.P), dim3(256), 0, ctx->stream, ps.p1, ps.p2, ps.match_cap,
+                       ps.m1, ps.m2, ps.st, 1, thr_px, 1);
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
