@@ -200,6 +200,10 @@ int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out);
 int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask,
                         int cap, double* Xk, int cap_world);
 
+/* Inspection of the context's last single-call RANSAC (tests): what = 0 tuples [4096][5] int32,
+ * 1 nmodels [4096] int32, 2 counts [4096][10] int32, 3 models [4096][10][9] double.              */
+int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes);
+
 /* Per-stage device timing (HIP events on the context's compute stream).  Enable, run,
  * sync, then read.  Stage names: vo_stage_name(i), i in [0, vo_stage_count()).           */
 int vo_profile_enable(vo_ctx* ctx, int on);

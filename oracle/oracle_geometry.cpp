@@ -478,7 +478,8 @@ static void normalise_points(const float* p, int n, const double K[9], std::vect
 
 // findEssentialMat(RANSAC) == RANSACPointSetRegistrator::run (A.8)
 int essential_ransac(const float* p1, const float* p2, int n, const double K[9], double prob, double thr_px,
-                     int max_iters, uint64_t seed, double E[9], uint8_t* mask, int* n_inl, int* iters_run) {
+                     int max_iters, uint64_t seed, double E[9], uint8_t* mask, int* n_inl, int* iters_run,
+                     const double* replay_models, const int* replay_nmodels) {
     if (n_inl) *n_inl = 0;
     if (iters_run) *iters_run = 0;
     if (n < 5) return VO_ERR_TOO_FEW_POINTS;
@@ -505,6 +506,24 @@ int essential_ransac(const float* p1, const float* p2, int n, const double K[9],
     const float t = (float)(threshold * threshold);
     int iter = 0;
     for (; iter < niters; iter++) {
+        if (replay_models) {
+            // replay mode (tests only): the candidate models of hypothesis `iter` are supplied by the
+            // caller instead of being solved here; the registrator loop is otherwise unchanged
+            int nmodels = replay_nmodels[iter];
+            const double* mdl = replay_models + (size_t)iter * 90;
+            for (int mi = 0; mi < nmodels; mi++) {
+                sampson_errors(m1.data(), m2.data(), n, mdl + 9 * mi, err.data());
+                int good = 0;
+                for (int i = 0; i < n; i++) good += (cur[i] = (uint8_t)(err[i] <= t));
+                if (good > std::max(maxGoodCount, modelPoints - 1)) {
+                    std::swap(cur, best);
+                    std::memcpy(bestE, mdl + 9 * mi, 9 * sizeof(double));
+                    maxGoodCount = good;
+                    niters = ransac_update_num_iters(prob, (double)(n - good) / n, modelPoints, niters);
+                }
+            }
+            continue;
+        }
         int idx[5];
         for (int i = 0; i < 5; i++) {
             int idx_i;

@@ -53,7 +53,8 @@ int five_point(const double x1[10], const double x2[10], double E_out[90]);
 void sampson_errors(const double* m1, const double* m2, int n, const double E[9], float* err);
 int ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters);
 int essential_ransac(const float* p1, const float* p2, int n, const double K[9], double prob, double thr_px,
-                     int max_iters, uint64_t seed, double E[9], uint8_t* mask, int* n_inl, int* iters_run);
+                     int max_iters, uint64_t seed, double E[9], uint8_t* mask, int* n_inl, int* iters_run,
+                     const double* replay_models = nullptr, const int* replay_nmodels = nullptr);
 int recover_pose(const double E[9], const float* p1, const float* p2, int n, const double K[9], double dist_thresh,
                  double R[9], double t[3], int* n_good);
 void triangulate(const double P0[12], const double P1[12], const double* x1, const double* y1, const double* x2,

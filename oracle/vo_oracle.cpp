@@ -152,6 +152,15 @@ int vo_oracle_essential_ransac(const float* p1xy, const float* p2xy, int n, cons
     return essential_ransac(p1xy, p2xy, n, K, prob, thr_px, max_iters, seed, E, mask, n_inl, iters_run);
 }
 
+// RANSACPointSetRegistrator::run with externally supplied candidate models per hypothesis
+// (models [max_iters][10][9], nmodels [max_iters]); used to check the GPU's scoring + sequential scan.
+int vo_oracle_ransac_replay(const float* p1xy, const float* p2xy, int n, const double K[9], double prob, double thr_px,
+                            int max_iters, const double* models, const int32_t* nmodels, double E[9], uint8_t* mask,
+                            int* n_inl, int* iters_run) {
+    if (!p1xy || !p2xy || !K || !E || !mask || !models || !nmodels || n <= 5) return VO_ERR_INVALID_ARG;
+    return essential_ransac(p1xy, p2xy, n, K, prob, thr_px, max_iters, 1, E, mask, n_inl, iters_run, models, nmodels);
+}
+
 int vo_oracle_recover_pose(const double E[9], const float* p1xy, const float* p2xy, int n, const double K[9],
                            double dist_thresh, double R[9], double t[3], int* n_good) {
     if (!E || !p1xy || !p2xy || !K || !R || !t || n < 0) return VO_ERR_INVALID_ARG;

@@ -39,6 +39,9 @@ int vo_oracle_sampson_masks(const float* p1xy, const float* p2xy, int n, const d
 int vo_oracle_essential_ransac(const float* p1xy, const float* p2xy, int n, const double K[9], double prob,
                                double thr_px, int max_iters, uint64_t seed, double E[9], uint8_t* mask,
                                int* n_inl, int* iters_run);
+int vo_oracle_ransac_replay(const float* p1xy, const float* p2xy, int n, const double K[9], double prob, double thr_px,
+                            int max_iters, const double* models, const int32_t* nmodels, double E[9], uint8_t* mask,
+                            int* n_inl, int* iters_run);
 int vo_oracle_recover_pose(const double E[9], const float* p1xy, const float* p2xy, int n, const double K[9],
                            double dist_thresh, double R[9], double t[3], int* n_good);
 int vo_oracle_relative_pose(const vo_params* p, const float* p1xy, const float* p2xy, int n, const double K[9],

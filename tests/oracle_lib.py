@@ -133,6 +133,22 @@ def essential_ransac(p1, p2, K, prob=0.99, thr_px=2.0, max_iters=1000, seed=2**6
     return st, E.reshape(3, 3), mask[:n], ninl.value, iters.value
 
 
+def ransac_replay(p1, p2, K, models, nmodels, prob=0.99, thr_px=2.0, max_iters=1000):
+    p1 = np.ascontiguousarray(p1, np.float32)
+    p2 = np.ascontiguousarray(p2, np.float32)
+    K = np.ascontiguousarray(K, np.float64)
+    models = np.ascontiguousarray(models, np.float64)
+    nmodels = np.ascontiguousarray(nmodels, np.int32)
+    assert models.shape[0] >= max_iters and len(nmodels) >= max_iters
+    n = len(p1)
+    E = np.zeros(9, np.float64)
+    mask = np.zeros(max(n, 1), np.uint8)
+    ninl, iters = C.c_int(0), C.c_int(0)
+    st = lib.vo_oracle_ransac_replay(_p(p1, f32p), _p(p2, f32p), n, _p(K, f64p), C.c_double(prob), C.c_double(thr_px), max_iters,
+                                     _p(models, f64p), _p(nmodels, i32p), _p(E, f64p), _p(mask, u8p), C.byref(ninl), C.byref(iters))
+    return st, E.reshape(3, 3), mask[:n], ninl.value, iters.value
+
+
 def recover_pose(E, p1, p2, K, dist_thresh=50.0):
     E = np.ascontiguousarray(E, np.float64)
     p1 = np.ascontiguousarray(p1, np.float32)

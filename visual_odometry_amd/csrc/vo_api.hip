@@ -797,3 +797,23 @@ extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2
     VO_HIP(hipStreamSynchronize(ctx->stream));
     return VO_OK;
 }
+
+// ---------------------------------------------------------------- inspection of the last single-call RANSAC
+// what: 0 = tuples [max_hyp][5] int32, 1 = nmodels [max_hyp] int32, 2 = counts [max_hyp][10] int32,
+//       3 = models [max_hyp][10][9] double.  Copies min(bytes, size) bytes of pair 0 of the context's scratch set.
+extern "C" int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes) {
+    if (!ctx || !dst || !ctx->ps.st) return VO_ERR_INVALID_ARG;
+    const PairSet& ps = ctx->ps;
+    const void* src = nullptr;
+    size_t size = 0;
+    switch (what) {
+        case 0: src = ps.tuples; size = (size_t)ps.max_hyp * 5 * sizeof(int); break;
+        case 1: src = ps.nmodels; size = (size_t)ps.max_hyp * sizeof(int); break;
+        case 2: src = ps.counts; size = (size_t)ps.max_hyp * kMaxModels * sizeof(int); break;
+        case 3: src = ps.models; size = (size_t)ps.max_hyp * kMaxModels * 9 * sizeof(double); break;
+        default: return VO_ERR_INVALID_ARG;
+    }
+    VO_HIP(hipSetDevice(ctx->device));
+    VO_HIP(hipMemcpy(dst, src, std::min(bytes, size), hipMemcpyDeviceToHost));
+    return VO_OK;
+}

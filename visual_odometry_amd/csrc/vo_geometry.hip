@@ -840,7 +840,9 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PairState* __restrict__ st, 
         S.best_hyp = best_h;
         S.best_model = best_m;
         S.scanned = max(S.scanned, min(h_end, niters));
-        S.iters_run = min(h_end, niters);
+        // loop counter of the sequential registrator at exit: the bound, or one past the hypothesis whose
+        // update pulled the bound below the current iteration
+        S.iters_run = best_h >= 0 ? max(min(h_end, niters), min(h_end, best_h + 1)) : min(h_end, niters);
     }
 }
 
