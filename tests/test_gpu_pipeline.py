@@ -1,0 +1,60 @@
+"""GPU parity of the device-resident batch pipeline (vo_batch_*: detect x2 -> match -> E-RANSAC -> recoverPose ->
+triangPoints with no host round trip) against the per-stage entry points and the CPU oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from visual_odometry_amd import synth
+from visual_odometry_amd.frontend import Batch, KpAsPoint2f_Match
+
+pytestmark = pytest.mark.gpu
+
+
+def _angle(Ra, Rb):
+    return np.degrees(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
+
+
+def test_batch_matches_stagewise_and_oracle(ctx):
+    scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 1001), (500, 3), (900, 4)]]
+    b = Batch(ctx, len(scenes), 480, 640)
+    for i, sc in enumerate(scenes):
+        b.set_pair(i, sc.img1, sc.img2, sc.K)
+    for rep in range(2):  # second run reuses every device buffer: nothing may leak between runs
+        b.run()
+        b.sync()
+        for i, sc in enumerate(scenes):
+            out = b.get(i)
+            p1, p2, m, mask, X = b.get_points(i)
+            rp1, rp2, rm = O.detect_match(sc.img1, sc.img2)
+            assert out.status == 0 and out.n_match == len(rm)
+            assert np.array_equal(p1, rp1) and np.array_equal(p2, rp2)
+            assert np.array_equal(m["queryIdx"], rm["queryIdx"]) and np.array_equal(m["trainIdx"], rm["trainIdx"])
+            # geometry of the batch == the single-call entry points on the same matches (bit for bit)
+            st, E, smask, ninl, iters = ctx.essential_ransac(p1, p2, sc.K)
+            assert st == 0 and np.array_equal(mask, smask) and out.n_inl == ninl and out.iters == iters
+            assert np.array_equal(np.array(out.E).reshape(3, 3), E)
+            st2, R, t, inl, ok = ctx.optRelativePose(KpAsPoint2f_Match(p1, p2, m), sc.K)
+            assert ok == bool(out.success)
+            if ok:
+                assert np.array_equal(np.array(out.R).reshape(3, 3), R) and np.array_equal(np.array(out.t), t)
+                Xs = ctx.triangPoints(inl.Kpoints1, inl.Kpoints2, R, t, sc.K)
+                assert X.shape == Xs.shape and np.array_equal(X, Xs)
+                Xr = O.triang_points(inl.Kpoints1, inl.Kpoints2, R, t, sc.K)
+                assert X.shape == Xr.shape and np.allclose(X, Xr, rtol=1e-5, atol=1e-6)
+            else:
+                assert out.n_world == 0
+    b.close()
+
+
+def test_batch_pose_close_to_ground_truth(ctx):
+    sc = synth.blob_scene(1080, 1920, synth.K_1080P, 2500, 2002)
+    ctx2_params = ctx.params
+    b = Batch(ctx, 1, 1080, 1920)
+    b.set_pair(0, sc.img1, sc.img2, sc.K)
+    b.run()
+    b.sync()
+    out = b.get(0)
+    assert out.status == 0 and out.n_match > 100
+    if out.success:
+        assert _angle(np.array(out.R).reshape(3, 3), sc.R) < 1.0
+    b.close()

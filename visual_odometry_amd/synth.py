@@ -99,12 +99,18 @@ def blob_scene(
     z = rng.uniform(depth[0], depth[1], size=n_blobs)
     s1 = np.exp(rng.uniform(np.log(sigma_px[0]), np.log(sigma_px[1]), size=n_blobs))
     amp = rng.uniform(30.0, 90.0, size=n_blobs) * rng.choice([-1.0, 1.0], size=n_blobs)
-    phi = rng.uniform(0, 2 * np.pi, size=n_blobs)
-    du = np.concatenate([np.zeros(n_blobs), 1.8 * s1 * np.cos(phi), 2.2 * s1 * np.cos(phi + 2.1)])
-    dv = np.concatenate([np.zeros(n_blobs), 1.8 * s1 * np.sin(phi), 2.2 * s1 * np.sin(phi + 2.1)])
-    ua, va, za = np.tile(u, 3) + du, np.tile(v, 3) + dv, np.tile(z, 3)
-    sa = np.concatenate([s1, 0.7 * s1, 0.6 * s1])
-    aa = np.concatenate([amp, 0.7 * amp, -0.5 * amp])
+    # three satellites per feature with random polar offset, size and signed amplitude: every feature gets
+    # its own asymmetric neighbourhood (distinct descriptors), rigidly attached to the 3-D point
+    ns = 3
+    phi = rng.uniform(0, 2 * np.pi, size=(ns, n_blobs))
+    rad = rng.uniform(1.2, 2.8, size=(ns, n_blobs)) * s1
+    sfac = rng.uniform(0.5, 0.9, size=(ns, n_blobs))
+    afac = rng.uniform(0.35, 0.9, size=(ns, n_blobs)) * rng.choice([-1.0, 1.0], size=(ns, n_blobs))
+    du = np.concatenate([np.zeros(n_blobs)] + [rad[k] * np.cos(phi[k]) for k in range(ns)])
+    dv = np.concatenate([np.zeros(n_blobs)] + [rad[k] * np.sin(phi[k]) for k in range(ns)])
+    ua, va, za = np.tile(u, ns + 1) + du, np.tile(v, ns + 1) + dv, np.tile(z, ns + 1)
+    sa = np.concatenate([s1] + [sfac[k] * s1 for k in range(ns)])
+    aa = np.concatenate([amp] + [afac[k] * amp for k in range(ns)])
     Kinv = np.linalg.inv(K)
     Xa = (Kinv @ np.stack([ua, va, np.ones_like(ua)])) * za  # [3, 3P]
     Xb = R @ Xa + t[:, None]
@@ -150,3 +156,19 @@ def surf_like_descriptors(n: int, seed: int) -> np.ndarray:
     d = d.reshape(n, 64)
     d /= np.linalg.norm(d, axis=1, keepdims=True)
     return d.astype(np.float32)
+
+
+# ---- named workloads of BASELINE.json / SURVEY.md 8d -------------------------------------------------------
+def scene_c1(seed: int = 1001) -> Scene:
+    """C1: Parete-like 640x480 pair, ~1k-2k keypoints, camera_intrinsic.yaml intrinsics."""
+    return blob_scene(480, 640, K_PARETE, 500, seed)
+
+
+def scene_c2(seed: int = 2002) -> Scene:
+    """C2 (headline): synthetic 1080p textured pair, 8192 +- 5 % keypoints per frame at minHessian = 50."""
+    return blob_scene(1080, 1920, K_1080P, 4300, seed, depth=(6.5, 8.5), baseline=0.3, sigma_px=(1.6, 5.0))
+
+
+def roi_for(h: int, w: int, border: float = 0.04):
+    """ROI of the reference scaled to the frame: the image minus a 4 % border."""
+    return (round(border * w), round(border * h), round((1 - border) * w), round((1 - border) * h))
