@@ -46,15 +46,31 @@ def test_batch_matches_stagewise_and_oracle(ctx):
     b.close()
 
 
-def test_batch_pose_close_to_ground_truth(ctx):
-    sc = synth.blob_scene(1080, 1920, synth.K_1080P, 2500, 2002)
-    ctx2_params = ctx.params
-    b = Batch(ctx, 1, 1080, 1920)
+def test_batch_1080p_pose_close_to_ground_truth_and_oracle():
+    """BASELINE config 2 workload: 1080p, ~8k keypoints per frame, ROI scaled to the frame."""
+    from visual_odometry_amd._abi import default_params
+    from visual_odometry_amd.frontend import Context
+
+    sc = synth.scene_c2(2002)
+    prm = default_params()
+    prm.roi_x_lo, prm.roi_y_lo, prm.roi_x_hi, prm.roi_y_hi = synth.roi_for(1080, 1920)
+    c = Context(prm)
+    b = Batch(c, 2, 1080, 1920)
     b.set_pair(0, sc.img1, sc.img2, sc.K)
+    b.set_pair(1, sc.img2, sc.img1, sc.K)
     b.run()
     b.sync()
     out = b.get(0)
-    assert out.status == 0 and out.n_match > 100
-    if out.success:
-        assert _angle(np.array(out.R).reshape(3, 3), sc.R) < 1.0
+    ref = O.pair(sc.img1, sc.img2, sc.K, prm)
+    assert out.status == 0
+    assert 0.95 * 8192 <= out.n_kp1 <= 1.05 * 8192
+    assert (out.n_kp1, out.n_kp2, out.n_match) == (ref.n_kp1, ref.n_kp2, ref.n_match)
+    assert out.success == ref.success == 1
+    R = np.array(out.R).reshape(3, 3)
+    assert _angle(R, np.array(ref.R).reshape(3, 3)) < 0.1  # north star: pose vs the reference path
+    assert _angle(R, sc.R) < 1.0
+    assert abs(out.n_inl - ref.n_inl) <= 0.05 * ref.n_inl
+    out1 = b.get(1)
+    assert out1.status == 0 and out1.n_kp1 == out.n_kp2 and out1.n_kp2 == out.n_kp1
     b.close()
+    c.close()

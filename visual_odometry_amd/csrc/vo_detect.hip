@@ -11,7 +11,7 @@
 //                            wavefront-ballot compaction of keypoints; nothing but the
 //                            keypoint list is written to HBM
 //   k_rank + k_scatter     : total-order rank sort (KeypointGreater)
-//   k_describe<>           : orientation + 64-float descriptor, one wavefront per keypoint,
+//   k_describe<>           : orientation + 64-float descriptor, one wavefront per keypoint (four for windows > 128 px),
 //                            rotated window sampled row-per-lane straight into the
 //                            INTER_AREA row accumulators held in LDS
 // Arithmetic follows the order of operations of SURVEY.md Appendix A exactly; the file is
@@ -573,17 +573,28 @@ __device__ __forceinline__ int sample_pixel(const uint8_t* __restrict__ img, int
 
 __device__ __forceinline__ int saturate_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
-template <int MAXWIN>
-__global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img_base, size_t img_stride,
+// Decimation table per SOURCE pixel column j (identical for every row of the window, and, applied to
+// rows, for the vertical pass): the pixel adds S*w_cur to the open destination cell; if it is the cell's
+// last pixel the cell is closed and the next one opens with S*w_next (the pixel's head share, or 0).
+struct PixTab {
+    float w_cur, w_next;
+    int end;
+};
+
+// WLO < win <= WHI selects the instance; NT threads cooperate on one keypoint (64 = one wavefront).
+template <int WLO, int WHI, int NT>
+__global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                  const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                  vo_keypoint* __restrict__ kp_base, float* __restrict__ desc_base,
                                                  int cap, const FrameCounters* __restrict__ cnt) {
     __shared__ float s_X[kOriSamples + 15], s_Y[kOriSamples + 15];
     __shared__ int s_A[kOriSamples + 15];
     __shared__ CellTab s_cell[kPatch + 1];
-    __shared__ float s_rowbuf[MAXWIN * (kPatch + 1)];  // float or int row accumulators; later DX/DY
+    __shared__ PixTab s_pix[WHI];
+    __shared__ float s_rowbuf[(WHI < 40 ? 40 : WHI) * (kPatch + 1)];  // float or int row accumulators; later DX/DY
     __shared__ uint8_t s_patch[(kPatch + 1) * (kPatch + 1) + 7];
     __shared__ float s_vec[64];
+    __shared__ float s_dir;
 
     const int frame = blockIdx.y, k = blockIdx.x;
     const int n = min(cnt[frame].n_raw, cap);
@@ -593,63 +604,65 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
     const float cx = kpp->x, cy = kpp->y;
     const float s = size * 1.2f / 9.0f;
     const int win = (int)((kPatch + 1) * s);
-    if (MAXWIN == kSmallWin ? (win > kSmallWin) : (win <= kSmallWin)) return;  // handled by the other instance
-    const int lane = threadIdx.x;
+    if (win <= WLO || win > WHI) return;  // handled by another instance
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
     const int sw = W + 1;
     const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
 
-    // ---------------------------------------------------------------- orientation (A.5)
-    const int g = 2 * d_cvRoundF(2 * s);
-    int nangle = 0;
-    if (!(H + 1 < g || W + 1 < g)) {
-        const int xm = g / 2;  // cvRound((float)g/4 * 2)
-        const float wxa = -1.f / ((float)xm * g), wxb = 1.f / ((float)(g - xm) * g);
-        const float wya = 1.f / ((float)g * xm), wyb = -1.f / ((float)g * (g - xm));
-        const float half = (float)(g - 1) / 2;
-        for (int pass = 0; pass < 2; pass++) {
-            const int kk = pass * 64 + lane;
-            bool inb = false;
-            float X = 0, Y = 0;
-            int Ar = 0;
-            if (kk < kOriSamples) {
-                const int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
-                const int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
-                inb = !(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g);
-                if (inb) {
-                    const int32_t* p = sum + (size_t)y * sw + x;
-                    const uint32_t t00 = p[0], t0m = p[xm], t0g = p[g];
-                    const uint32_t tm0 = p[(size_t)xm * sw], tmg = p[(size_t)xm * sw + g];
-                    const uint32_t tg0 = p[(size_t)g * sw], tgm = p[(size_t)g * sw + xm], tgg = p[(size_t)g * sw + g];
-                    // dx: boxes x[0,xm] (w<0) and x[xm,g] (w>0), both y[0,g]
-                    const int bxa = (int)(t00 + tgm - tg0 - t0m), bxb = (int)(t0m + tgg - tgm - t0g);
-                    double d = (double)((float)bxa * wxa);
-                    d += (double)((float)bxb * wxb);
-                    const float vx = (float)d;
-                    // dy: boxes y[0,xm] (w>0) and y[xm,g] (w<0), both x[0,g]
-                    const int bya = (int)(t00 + tmg - tm0 - t0g), byb = (int)(tm0 + tgg - tg0 - tmg);
-                    d = (double)((float)bya * wya);
-                    d += (double)((float)byb * wyb);
-                    const float vy = (float)d;
-                    const float w = c_tab.aptw[kk];
-                    X = vx * w;
-                    Y = vy * w;
-                    Ar = d_cvRoundF(d_fastAtan2(Y, X));
+    // ---------------------------------------------------------------- orientation (A.5), first wavefront
+    if (tid < 64) {
+        const int g = 2 * d_cvRoundF(2 * s);
+        int nangle = 0;
+        if (!(H + 1 < g || W + 1 < g)) {
+            const int xm = g / 2;  // cvRound((float)g/4 * 2)
+            const float wxa = -1.f / ((float)xm * g), wxb = 1.f / ((float)(g - xm) * g);
+            const float wya = 1.f / ((float)g * xm), wyb = -1.f / ((float)g * (g - xm));
+            const float half = (float)(g - 1) / 2;
+            for (int pass = 0; pass < 2; pass++) {
+                const int kk = pass * 64 + lane;
+                bool inb = false;
+                float X = 0, Y = 0;
+                int Ar = 0;
+                if (kk < kOriSamples) {
+                    const int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
+                    const int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
+                    inb = !(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g);
+                    if (inb) {
+                        const int32_t* p = sum + (size_t)y * sw + x;
+                        const uint32_t t00 = p[0], t0m = p[xm], t0g = p[g];
+                        const uint32_t tm0 = p[(size_t)xm * sw], tmg = p[(size_t)xm * sw + g];
+                        const uint32_t tg0 = p[(size_t)g * sw], tgm = p[(size_t)g * sw + xm], tgg = p[(size_t)g * sw + g];
+                        // dx: boxes x[0,xm] (w<0) and x[xm,g] (w>0), both y[0,g]
+                        const int bxa = (int)(t00 + tgm - tg0 - t0m), bxb = (int)(t0m + tgg - tgm - t0g);
+                        double d = (double)((float)bxa * wxa);
+                        d += (double)((float)bxb * wxb);
+                        const float vx = (float)d;
+                        // dy: boxes y[0,xm] (w>0) and y[xm,g] (w<0), both x[0,g]
+                        const int bya = (int)(t00 + tmg - tm0 - t0g), byb = (int)(tm0 + tgg - tg0 - tmg);
+                        d = (double)((float)bya * wya);
+                        d += (double)((float)byb * wyb);
+                        const float vy = (float)d;
+                        const float w = c_tab.aptw[kk];
+                        X = vx * w;
+                        Y = vy * w;
+                        Ar = d_cvRoundF(d_fastAtan2(Y, X));
+                    }
                 }
+                const unsigned long long m = __ballot(inb);
+                if (inb) {
+                    const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
+                    s_X[pos] = X;
+                    s_Y[pos] = Y;
+                    s_A[pos] = Ar;
+                }
+                nangle += __popcll(m);
             }
-            const unsigned long long m = __ballot(inb);
-            if (inb) {
-                const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
-                s_X[pos] = X;
-                s_Y[pos] = Y;
-                s_A[pos] = Ar;
-            }
-            nangle += __popcll(m);
         }
-    }
-    __syncthreads();
-    float descriptor_dir;
-    {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         float best_mod = 0.f, best_x = 0.f, best_y = 0.f;
         int best_i = 1 << 30;
         for (int pass = 0; pass < 2; pass++) {
@@ -690,26 +703,20 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
             best_x = 0.f;
             best_y = 0.f;
         }
-        descriptor_dir = d_fastAtan2(-best_y, best_x);
+        const float dd = d_fastAtan2(-best_y, best_x);
+        if (tid == 0) {
+            kpp->angle = dd;
+            s_dir = dd;
+        }
     }
-    if (lane == 0) kpp->angle = descriptor_dir;
     if (desc_base == nullptr) return;
 
-    // ---------------------------------------------------------------- descriptor (A.6)
-    const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
-    // sin/cos(float) defined as the double function rounded to float (see oracle_surf.cpp)
-    const float sin_dir = -(float)sin((double)dir);
-    const float cos_dir = (float)cos((double)dir);
-    const float win_offset = -(float)(win - 1) / 2;
-    float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
-    float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
-    const int ncols1 = W - 1, nrows1 = H - 1;
-
+    // ---------------------------------------------------------------- decimation tables (A.6.1)
     const double scale = (double)win / (kPatch + 1);
     const int iscale = d_cvRoundD(scale);
     const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
-    if (!area_fast && lane <= kPatch) {  // computeResizeAreaTab, one destination cell per lane
-        const int dxc = lane;
+    if (!area_fast && tid <= kPatch) {  // computeResizeAreaTab, one destination cell per thread
+        const int dxc = tid;
         const double fsx1 = dxc * scale, fsx2 = fsx1 + scale;
         const double cellWidth = fmin(scale, (double)win - fsx1);
         int sx1 = d_cvCeilD(fsx1), sx2 = d_cvFloorD(fsx2);
@@ -727,74 +734,103 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
         s_cell[dxc] = c;
     }
     __syncthreads();
+    if (!area_fast) {
+        for (int j = tid; j < win; j += NT) {
+            // the (at most two) table entries that read source pixel j, in destination order
+            PixTab t;
+            t.w_cur = 0.f;
+            t.w_next = 0.f;
+            t.end = 0;
+            bool have = false;
+#pragma unroll 1
+            for (int c = 0; c <= kPatch; c++) {
+                const CellTab ct = s_cell[c];
+                float w = 0.f;
+                bool hit = false;
+                if (ct.has_head && j == ct.sx1 - 1) {
+                    w = ct.a_head;
+                    hit = true;
+                } else if (j >= ct.sx1 && j < ct.sx2) {
+                    w = ct.a_mid;
+                    hit = true;
+                } else if (ct.has_tail && j == ct.sx2) {
+                    w = ct.a_tail;
+                    hit = true;
+                }
+                if (hit) {
+                    if (!have) {
+                        have = true;
+                        t.w_cur = w;
+                        const int last = ct.has_tail ? ct.sx2 : ct.sx2 - 1;
+                        t.end = (j == last) ? 1 : 0;
+                    } else {
+                        t.w_next = w;
+                    }
+                }
+            }
+            s_pix[j] = t;
+        }
+    }
+    __syncthreads();
 
-    // rows of the window: lane <-> row, columns walked sequentially so that the double
-    // coordinate accumulation (pixel_x += cos_dir) is reproduced step for step.
-    for (int r = 0; r < lane; r++) {
+    // ---------------------------------------------------------------- descriptor window (A.6)
+    const float descriptor_dir = s_dir;
+    const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
+    // sin/cos(float) defined as the double function rounded to float (see oracle_surf.cpp)
+    const float sin_dir = -(float)sin((double)dir);
+    const float cos_dir = (float)cos((double)dir);
+    const float win_offset = -(float)(win - 1) / 2;
+    float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
+    float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
+    const int ncols1 = W - 1, nrows1 = H - 1;
+
+    // rows of the window: thread <-> row, columns walked sequentially so that the double coordinate
+    // accumulation (pixel_x += cos_dir) is reproduced step for step; the row never exists as pixels,
+    // it is folded straight into the 21 horizontal accumulators of the INTER_AREA row pass.
+#pragma unroll 1
+    for (int r = 0; r < tid; r++) {
         start_x += sin_dir;
         start_y += cos_dir;
     }
     int* s_rowint = reinterpret_cast<int*>(s_rowbuf);
     const double dcos = (double)cos_dir, dsin = (double)sin_dir;
-    for (int base = 0; base < win; base += 64) {
-        const int i = base + lane;
+    for (int base = 0; base < win; base += NT) {
+        const int i = base + tid;
         if (i < win) {
             double px = (double)start_x, py = (double)start_y;
-            int cur = 0;
-            int S = sample_pixel(img, W, ncols1, nrows1, px, py);
             if (area_fast) {
-                for (int dxc = 0; dxc <= kPatch; dxc++) {
-                    int acc = 0;
-                    const int end = (dxc + 1) * iscale;
-                    for (int sx = dxc * iscale; sx < end; sx++) {
-                        while (cur < sx) {
-                            cur++;
-                            px += dcos;
-                            py -= dsin;
-                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
-                        }
-                        acc += S;
+                int acc = 0, c = 0, left = iscale;
+                for (int j = 0; j < win; j++) {
+                    acc += sample_pixel(img, W, ncols1, nrows1, px, py);
+                    px += dcos;
+                    py -= dsin;
+                    if (--left == 0) {
+                        s_rowint[i * (kPatch + 1) + c] = acc;
+                        c++;
+                        acc = 0;
+                        left = iscale;
                     }
-                    s_rowint[i * (kPatch + 1) + dxc] = acc;
                 }
             } else {
-                for (int dxc = 0; dxc <= kPatch; dxc++) {
-                    const CellTab c = s_cell[dxc];
-                    float acc = 0.f;
-                    if (c.has_head) {
-                        const int si = c.sx1 - 1;
-                        while (cur < si) {
-                            cur++;
-                            px += dcos;
-                            py -= dsin;
-                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
-                        }
-                        acc += (float)S * c.a_head;
+                float acc = 0.f;
+                int c = 0;
+#pragma unroll 4
+                for (int j = 0; j < win; j++) {
+                    const float S = (float)sample_pixel(img, W, ncols1, nrows1, px, py);
+                    px += dcos;
+                    py -= dsin;
+                    const PixTab t = s_pix[j];
+                    acc += S * t.w_cur;
+                    if (t.end) {  // uniform over the wavefront: every lane is at the same column
+                        s_rowbuf[i * (kPatch + 1) + c] = acc;
+                        c++;
+                        acc = S * t.w_next;
                     }
-                    for (int sx = c.sx1; sx < c.sx2; sx++) {
-                        while (cur < sx) {
-                            cur++;
-                            px += dcos;
-                            py -= dsin;
-                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
-                        }
-                        acc += (float)S * c.a_mid;
-                    }
-                    if (c.has_tail) {
-                        const int si = c.sx2;
-                        while (cur < si) {
-                            cur++;
-                            px += dcos;
-                            py -= dsin;
-                            S = sample_pixel(img, W, ncols1, nrows1, px, py);
-                        }
-                        acc += (float)S * c.a_tail;
-                    }
-                    s_rowbuf[i * (kPatch + 1) + dxc] = acc;
                 }
             }
         }
-        for (int r = 0; r < 64; r++) {  // this lane's next row is 64 rows further down
+#pragma unroll 1
+        for (int r = 0; r < NT; r++) {  // this thread's next row is NT rows further down
             start_x += sin_dir;
             start_y += cos_dir;
         }
@@ -802,7 +838,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
     __syncthreads();
 
     // vertical pass of the decimation: one destination pixel per work item
-    for (int it = lane; it < (kPatch + 1) * (kPatch + 1); it += 64) {
+    for (int it = tid; it < (kPatch + 1) * (kPatch + 1); it += NT) {
         const int dy = it / (kPatch + 1), dxc = it - dy * (kPatch + 1);
         int out;
         if (area_fast) {
@@ -829,7 +865,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
     // gradients weighted by the Gaussian (DX into s_rowbuf[0..399], DY into [400..799])
     float* s_DX = s_rowbuf;
     float* s_DY = s_rowbuf + kPatch * kPatch;
-    for (int it = lane; it < kPatch * kPatch; it += 64) {
+    for (int it = tid; it < kPatch * kPatch; it += NT) {
         const int i = it / kPatch, j = it - i * kPatch;
         const float dw = c_tab.DW[it];
         const int p00 = s_patch[i * (kPatch + 1) + j], p01 = s_patch[i * (kPatch + 1) + j + 1];
@@ -838,7 +874,7 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
         s_DY[it] = (float)(p10 - p00 + p11 - p01) * dw;
     }
     __syncthreads();
-    {
+    if (tid < 64) {
         // lane = cell*4 + q : 25 sequential float adds per lane, the order of the reference loops
         const int cell = lane >> 2, q = lane & 3;
         const int ci = cell >> 2, cj = cell & 3;
@@ -852,13 +888,15 @@ __global__ __launch_bounds__(64) void k_describe(const uint8_t* __restrict__ img
         s_vec[lane] = acc;
     }
     __syncthreads();
-    double square_mag = 0;
-    for (int kk = 0; kk < 64; kk++) {
-        const float v = s_vec[kk];
-        square_mag += (double)(v * v);
+    if (tid < 64) {
+        double square_mag = 0;
+        for (int kk = 0; kk < 64; kk++) {
+            const float v = s_vec[kk];
+            square_mag += (double)(v * v);
+        }
+        const float nscale = (float)(1. / (sqrt(square_mag) + (double)FLT_EPSILON));
+        desc_base[((size_t)frame * cap + k) * 64 + lane] = s_vec[lane] * nscale;
     }
-    const float nscale = (float)(1. / (sqrt(square_mag) + (double)FLT_EPSILON));
-    desc_base[((size_t)frame * cap + k) * 64 + lane] = s_vec[lane] * nscale;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -897,10 +935,13 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         StageScope sc(ctx, ST_DESCRIBE);
         float* d = describe ? fs.desc : nullptr;
         if (describe) {
-            hipLaunchKernelGGL(k_describe<kSmallWin>, dim3(fs.cap, fs.F), dim3(64), 0, ctx->stream, fs.img,
-                               fs.img_stride(), fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cnt);
-            hipLaunchKernelGGL(k_describe<kBigWin>, dim3(fs.cap, fs.F), dim3(64), 0, ctx->stream, fs.img,
-                               fs.img_stride(), fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cnt);
+#define LAUNCH_DESC(LO, HI, NT)                                                                                   \
+    hipLaunchKernelGGL((k_describe<LO, HI, NT>), dim3(fs.cap, fs.F), dim3(NT), 0, ctx->stream, fs.img, fs.img_stride(), \
+                       fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cnt)
+            LAUNCH_DESC(0, 64, 64);
+            LAUNCH_DESC(64, kSmallWin, 64);
+            LAUNCH_DESC(kSmallWin, kBigWin, 256);
+#undef LAUNCH_DESC
             VO_HIP(hipGetLastError());
         }
     }
