@@ -137,7 +137,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     fs.W = W;
     fs.cap = cap;
     const int nbands = (H + 15) / 16;
-    VO_TRY(dalloc(fs.img, (size_t)F * H * W + 64));
+    VO_TRY(dalloc(fs.img, (size_t)F * H * W + 256));  // tile staging may read up to 111 bytes past a row end
     VO_TRY(dalloc(fs.sum, (size_t)F * (H + 1) * (W + 1) + 64));
     VO_TRY(dalloc(fs.colsum, (size_t)F * nbands * W));
     VO_TRY(dalloc(fs.kp_raw, (size_t)F * cap));
@@ -147,6 +147,8 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.descT, (size_t)F * cap * 64));
     VO_TRY(dalloc(fs.nrm, (size_t)F * cap));
     VO_TRY(dalloc(fs.cnt, (size_t)F));
+    VO_TRY(dalloc(fs.cls_list, (size_t)4 * F * cap));
+    VO_TRY(dalloc(fs.cls_cnt, (size_t)8));
     VO_HIP(hipMemset(fs.rank, 0, (size_t)F * cap * sizeof(int)));
     VO_HIP(hipMemset(fs.cnt, 0, (size_t)F * sizeof(FrameCounters)));
     return VO_OK;
@@ -163,6 +165,8 @@ void vo_frameset_free(FrameSet& fs) {
     dfree(fs.descT);
     dfree(fs.nrm);
     dfree(fs.cnt);
+    dfree(fs.cls_list);
+    dfree(fs.cls_cnt);
     fs.F = fs.H = fs.W = fs.cap = 0;
 }
 
@@ -250,6 +254,7 @@ static int upload_frame(vo_ctx* ctx, FrameSet& fs, int frame, const uint8_t* img
 
 static int reset_counters(vo_ctx* ctx, FrameSet& fs) {
     VO_HIP(hipMemsetAsync(fs.cnt, 0, (size_t)fs.F * sizeof(FrameCounters), ctx->stream));
+    VO_HIP(hipMemsetAsync(fs.cls_cnt, 0, 8 * sizeof(int), ctx->stream));
     return VO_OK;
 }
 

@@ -123,6 +123,8 @@ struct FrameSet {
     float* descT = nullptr;         // [F][cap/32][8][64][4] MFMA operand layout + norms
     float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
     FrameCounters* cnt = nullptr;   // [F]
+    int* cls_list = nullptr;        // [4][F*cap] keypoints (frame*cap + k) of each descriptor window class
+    int* cls_cnt = nullptr;         // [8] list lengths, then work-queue tickets
     size_t img_stride() const { return (size_t)H * W; }
     size_t sum_stride() const { return (size_t)(H + 1) * (W + 1); }
 };
