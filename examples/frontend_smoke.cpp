@@ -11,9 +11,10 @@ int main() {
     std::vector<uint8_t> a((size_t)H * W, 128), b((size_t)H * W, 128);
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) & 0xffff; };
-    for (int k = 0; k < 400; k++) {  // random spots, second frame shifted by (25, 3) px
+    for (int k = 0; k < 400; k++) {  // random spots at different depths: camera moves along x, disparity 10..40 px
         const int cx = 40 + rnd() % (W - 100), cy = 40 + rnd() % (H - 80), amp = 40 + rnd() % 60;
         const double sg = 1.5 + (rnd() % 300) / 100.0;
+        const int disp = 10 + rnd() % 31;
         for (int y = -12; y <= 12; y++)
             for (int x = -12; x <= 12; x++) {
                 const int v = (int)(amp * std::exp(-(x * x + y * y) / (2 * sg * sg)));
@@ -21,7 +22,7 @@ int main() {
                     if (px >= 0 && px < W && py >= 0 && py < H) im[(size_t)py * W + px] = (uint8_t)std::min(255, im[(size_t)py * W + px] + v);
                 };
                 put(a, cx + x, cy + y);
-                put(b, cx + x + 25, cy + y + 3);
+                put(b, cx + x - disp, cy + y);
             }
     }
     try {

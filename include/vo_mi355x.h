@@ -203,6 +203,10 @@ int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmat
 /* Inspection of the context's last single-call RANSAC (tests): what = 0 tuples [4096][5] int32,
  * 1 nmodels [4096] int32, 2 counts [4096][10] int32, 3 models [4096][10][9] double.              */
 int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes);
+/* Test hook, no counterpart in the reference.  key 0: value != 0 sends EVERY keypoint's descriptor window
+ * through the sequential coordinate walk (the path otherwise taken only when the closed-form window
+ * coordinates are not exactly representable); results are identical either way.                         */
+int vo_debug_set(vo_ctx* ctx, int key, int value);
 
 /* Per-stage device timing (HIP events on the context's compute stream).  Enable, run,
  * sync, then read.  Stage names: vo_stage_name(i), i in [0, vo_stage_count()).           */

@@ -81,3 +81,21 @@ def test_capacity_error(ctx):
     with pytest.raises(VoError) as e:
         ctx.detect_describe(sc.img1, cap=10)
     assert e.value.status == -4
+
+
+@pytest.mark.gpu
+def test_describe_sequential_walk_matches_tiled(ctx):
+    """vo_debug_set key 0 routes every keypoint through the sequential window walk (the fallback for windows
+    whose closed-form coordinates are not exact); both walks must give bit-identical angles and descriptors."""
+    from visual_odometry_amd import synth
+
+    sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 4242)
+    kp_a, d_a = ctx.detect_describe(sc.img1)
+    ctx.debug_set(0, 1)
+    try:
+        kp_b, d_b = ctx.detect_describe(sc.img1)
+    finally:
+        ctx.debug_set(0, 0)
+    assert len(kp_a) == len(kp_b) > 100
+    assert np.array_equal(kp_a["angle"], kp_b["angle"])
+    assert np.array_equal(d_a, d_b)

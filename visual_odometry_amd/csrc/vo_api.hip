@@ -147,8 +147,8 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.descT, (size_t)F * cap * 64));
     VO_TRY(dalloc(fs.nrm, (size_t)F * cap));
     VO_TRY(dalloc(fs.cnt, (size_t)F));
-    VO_TRY(dalloc(fs.cls_list, (size_t)4 * F * cap));
-    VO_TRY(dalloc(fs.cls_cnt, (size_t)8));
+    VO_TRY(dalloc(fs.cls_list, (size_t)5 * F * cap));
+    VO_TRY(dalloc(fs.cls_cnt, (size_t)16));
     VO_HIP(hipMemset(fs.rank, 0, (size_t)F * cap * sizeof(int)));
     VO_HIP(hipMemset(fs.cnt, 0, (size_t)F * sizeof(FrameCounters)));
     return VO_OK;
@@ -254,7 +254,7 @@ static int upload_frame(vo_ctx* ctx, FrameSet& fs, int frame, const uint8_t* img
 
 static int reset_counters(vo_ctx* ctx, FrameSet& fs) {
     VO_HIP(hipMemsetAsync(fs.cnt, 0, (size_t)fs.F * sizeof(FrameCounters), ctx->stream));
-    VO_HIP(hipMemsetAsync(fs.cls_cnt, 0, 8 * sizeof(int), ctx->stream));
+    VO_HIP(hipMemsetAsync(fs.cls_cnt, 0, 16 * sizeof(int), ctx->stream));
     return VO_OK;
 }
 
@@ -821,4 +821,12 @@ extern "C" int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes) {
     VO_HIP(hipSetDevice(ctx->device));
     VO_HIP(hipMemcpy(dst, src, std::min(bytes, size), hipMemcpyDeviceToHost));
     return VO_OK;
+}
+
+extern "C" int vo_debug_set(vo_ctx* ctx, int key, int value) {
+    if (!ctx) return VO_ERR_INVALID_ARG;
+    switch (key) {
+        case 0: ctx->force_seq_describe = value ? 1 : 0; return VO_OK;
+        default: return VO_ERR_INVALID_ARG;
+    }
 }

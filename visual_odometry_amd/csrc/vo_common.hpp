@@ -123,8 +123,8 @@ struct FrameSet {
     float* descT = nullptr;         // [F][cap/32][8][64][4] MFMA operand layout + norms
     float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
     FrameCounters* cnt = nullptr;   // [F]
-    int* cls_list = nullptr;        // [4][F*cap] keypoints (frame*cap + k) of each descriptor window class
-    int* cls_cnt = nullptr;         // [8] list lengths, then work-queue tickets
+    int* cls_list = nullptr;        // [5][F*cap] keypoints (frame*cap + k) of each descriptor window class; list 4 = sequential-walk fallback
+    int* cls_cnt = nullptr;         // [16] list lengths [0..4], work-queue tickets [8..12]
     size_t img_stride() const { return (size_t)H * W; }
     size_t sum_stride() const { return (size_t)(H + 1) * (W + 1); }
 };
@@ -163,6 +163,7 @@ struct vo_ctx {
     DetectTables* d_tables = nullptr;
     uint32_t* d_rng_raw = nullptr;  // unused placeholder (rng stream is generated on device)
     bool profiling = false;
+    int force_seq_describe = 0;     // vo_debug_set key 0
     StageTimer timers[ST_COUNT];
     // lazily sized scratch for the single-call entry points
     FrameSet fs;

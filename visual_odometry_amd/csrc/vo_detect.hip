@@ -632,6 +632,217 @@ struct PixTab {
     int end;
 };
 
+// orientation (A.5) of one keypoint by one wavefront; writes kpp->angle and *s_dir (lane 0)
+__device__ __forceinline__ void describe_orientation(const int32_t* __restrict__ sum, int sw, int H, int W, float cx, float cy,
+                                                     float s, int lane, int tid, float* s_X, float* s_Y, int* s_A,
+                                                     vo_keypoint* kpp, float* s_dir_p) {
+    const int g = 2 * d_cvRoundF(2 * s);
+    int nangle = 0;
+    if (!(H + 1 < g || W + 1 < g)) {
+        const int xm = g / 2;  // cvRound((float)g/4 * 2)
+        const float wxa = -1.f / ((float)xm * g), wxb = 1.f / ((float)(g - xm) * g);
+        const float wya = 1.f / ((float)g * xm), wyb = -1.f / ((float)g * (g - xm));
+        const float half = (float)(g - 1) / 2;
+        for (int pass = 0; pass < 2; pass++) {
+            const int kk = pass * 64 + lane;
+            bool inb = false;
+            float X = 0, Y = 0;
+            int Ar = 0;
+            if (kk < kOriSamples) {
+                const int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
+                const int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
+                inb = !(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g);
+                if (inb) {
+                    const int32_t* p = sum + (size_t)y * sw + x;
+                    const uint32_t t00 = p[0], t0m = p[xm], t0g = p[g];
+                    const uint32_t tm0 = p[(size_t)xm * sw], tmg = p[(size_t)xm * sw + g];
+                    const uint32_t tg0 = p[(size_t)g * sw], tgm = p[(size_t)g * sw + xm], tgg = p[(size_t)g * sw + g];
+                    // dx: boxes x[0,xm] (w<0) and x[xm,g] (w>0), both y[0,g]
+                    const int bxa = (int)(t00 + tgm - tg0 - t0m), bxb = (int)(t0m + tgg - tgm - t0g);
+                    double d = (double)((float)bxa * wxa);
+                    d += (double)((float)bxb * wxb);
+                    const float vx = (float)d;
+                    // dy: boxes y[0,xm] (w>0) and y[xm,g] (w<0), both x[0,g]
+                    const int bya = (int)(t00 + tmg - tm0 - t0g), byb = (int)(tm0 + tgg - tg0 - tmg);
+                    d = (double)((float)bya * wya);
+                    d += (double)((float)byb * wyb);
+                    const float vy = (float)d;
+                    const float w = c_tab.aptw[kk];
+                    X = vx * w;
+                    Y = vy * w;
+                    Ar = d_cvRoundF(d_fastAtan2(Y, X));
+                }
+            }
+            const unsigned long long m = __ballot(inb);
+            if (inb) {
+                const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
+                s_X[pos] = X;
+                s_Y[pos] = Y;
+                s_A[pos] = Ar;
+            }
+            nangle += __popcll(m);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    float best_mod = 0.f, best_x = 0.f, best_y = 0.f;
+    int best_i = 1 << 30;
+    {
+        // 72 windows, one pass: lane L sums window L and (lanes 0..7) window L + 64.  Samples outside a
+        // window add +0.f, which leaves a float sum bit-identical to skipping them.
+        const int i0 = lane * 5, i1 = (lane + 64) * 5;
+        float sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
+#pragma unroll 4
+        for (int j = 0; j < nangle; j++) {
+            const int A = s_A[j];
+            const float X = s_X[j], Y = s_Y[j];
+            const int d0 = abs(A - i0), d1 = abs(A - i1);
+            const bool in0 = d0 < 30 || d0 > 330, in1 = d1 < 30 || d1 > 330;
+            sx0 += in0 ? X : 0.f;
+            sy0 += in0 ? Y : 0.f;
+            sx1 += in1 ? X : 0.f;
+            sy1 += in1 ? Y : 0.f;
+        }
+        const float m0 = sx0 * sx0 + sy0 * sy0;
+        if (m0 > best_mod) {
+            best_mod = m0;
+            best_x = sx0;
+            best_y = sy0;
+            best_i = i0;
+        }
+        const float m1 = sx1 * sx1 + sy1 * sy1;
+        if (lane < 8 && m1 > best_mod) {  // i1 > i0: strictly greater only
+            best_mod = m1;
+            best_x = sx1;
+            best_y = sy1;
+            best_i = i1;
+        }
+    }
+    // first strict maximum over all windows: larger mod wins, ties go to the smaller i
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        const float om = __shfl_xor(best_mod, d, 64), ox = __shfl_xor(best_x, d, 64),
+                    oy = __shfl_xor(best_y, d, 64);
+        const int oi = __shfl_xor(best_i, d, 64);
+        if (om > best_mod || (om == best_mod && oi < best_i)) {
+            best_mod = om;
+            best_x = ox;
+            best_y = oy;
+            best_i = oi;
+        }
+    }
+    if (!(best_mod > 0.f)) {
+        best_x = 0.f;
+        best_y = 0.f;
+    }
+    const float dd = d_fastAtan2(-best_y, best_x);
+    if (tid == 0) {
+        kpp->angle = dd;
+        *s_dir_p = dd;
+    }
+}
+
+// computeResizeAreaTab (A.6.1): one destination cell per thread (tid <= kPatch)
+__device__ __forceinline__ void describe_cell_tab(int tid, int win, double scale, CellTab* s_cell) {
+    const int dxc = tid;
+    const double fsx1 = dxc * scale, fsx2 = fsx1 + scale;
+    const double cellWidth = fmin(scale, (double)win - fsx1);
+    int sx1 = d_cvCeilD(fsx1), sx2 = d_cvFloorD(fsx2);
+    sx2 = min(sx2, win - 1);
+    sx1 = min(sx1, sx2);
+    CellTab c;
+    c.sx1 = sx1;
+    c.sx2 = sx2;
+    c.has_head = (sx1 - fsx1 > 1e-3);
+    c.a_head = (float)((sx1 - fsx1) / cellWidth);
+    c.a_mid = (float)(1.0 / cellWidth);
+    c.has_tail = (fsx2 - sx2 > 1e-3);
+    c.a_tail = (float)(fmin(fmin(fsx2 - sx2, 1.), cellWidth) / cellWidth);
+    c.pad = 0;
+    s_cell[dxc] = c;
+}
+
+// per-source-pixel view of the same table (see PixTab)
+__device__ __forceinline__ void describe_pix_tab(int tid, int NT, int win, const CellTab* s_cell, PixTab* s_pix) {
+    for (int j = tid; j < win; j += NT) {
+        // the (at most two) table entries that read source pixel j, in destination order
+        PixTab t;
+        t.w_cur = 0.f;
+        t.w_next = 0.f;
+        t.end = 0;
+        bool have = false;
+#pragma unroll 1
+        for (int c = 0; c <= kPatch; c++) {
+            const CellTab ct = s_cell[c];
+            float w = 0.f;
+            bool hit = false;
+            if (ct.has_head && j == ct.sx1 - 1) {
+                w = ct.a_head;
+                hit = true;
+            } else if (j >= ct.sx1 && j < ct.sx2) {
+                w = ct.a_mid;
+                hit = true;
+            } else if (ct.has_tail && j == ct.sx2) {
+                w = ct.a_tail;
+                hit = true;
+            }
+            if (hit) {
+                if (!have) {
+                    have = true;
+                    t.w_cur = w;
+                    const int last = ct.has_tail ? ct.sx2 : ct.sx2 - 1;
+                    t.end = (j == last) ? 1 : 0;
+                } else {
+                    t.w_next = w;
+                }
+            }
+        }
+        s_pix[j] = t;
+    }
+}
+
+// 21x21 patch -> Gaussian-weighted gradients -> 4x4 cells x (dx, dy, |dx|, |dy|) -> unit vector (A.6.2, A.6.3).
+// Called by every thread of the workgroup (contains barriers); s_grad holds 2 * 400 floats.
+__device__ __forceinline__ void describe_patch_to_vec(int tid, int NT, const uint8_t* s_patch, float* s_grad, float* s_vec,
+                                                      float* __restrict__ desc_out) {
+    const int lane = tid & 63;
+    float* s_DX = s_grad;
+    float* s_DY = s_grad + kPatch * kPatch;
+    for (int it = tid; it < kPatch * kPatch; it += NT) {
+        const int i = it / kPatch, j = it - i * kPatch;
+        const float dw = c_tab.DW[it];
+        const int p00 = s_patch[i * (kPatch + 1) + j], p01 = s_patch[i * (kPatch + 1) + j + 1];
+        const int p10 = s_patch[(i + 1) * (kPatch + 1) + j], p11 = s_patch[(i + 1) * (kPatch + 1) + j + 1];
+        s_DX[it] = (float)(p01 - p00 + p11 - p10) * dw;
+        s_DY[it] = (float)(p10 - p00 + p11 - p01) * dw;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        // lane = cell*4 + q : 25 sequential float adds per lane, the order of the reference loops
+        const int cell = lane >> 2, q = lane & 3;
+        const int ci = cell >> 2, cj = cell & 3;
+        float acc = 0.f;
+        for (int y = ci * 5; y < ci * 5 + 5; y++)
+            for (int x = cj * 5; x < cj * 5 + 5; x++) {
+                const float tx = s_DX[y * kPatch + x], ty = s_DY[y * kPatch + x];
+                const float v = q == 0 ? tx : (q == 1 ? ty : (q == 2 ? fabsf(tx) : fabsf(ty)));
+                acc += v;
+            }
+        s_vec[lane] = acc;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double square_mag = 0;
+        for (int kk = 0; kk < 64; kk++) {
+            const float v = s_vec[kk];
+            square_mag += (double)(v * v);
+        }
+        const float nscale = (float)(1. / (sqrt(square_mag) + (double)FLT_EPSILON));
+        desc_out[lane] = s_vec[lane] * nscale;
+    }
+}
+
 // WLO < win <= WHI selects the instance; NT threads cooperate on one keypoint (64 = one wavefront).
 template <int WLO, int WHI, int NT>
 __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img_base, size_t img_stride,
@@ -657,7 +868,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     // workgroup leaves as soon as its ticket is past the end of the list
     for (;;) {
     __syncthreads();  // previous keypoint's LDS is no longer read
-    if (tid == 0) s_item = atomicAdd(&cls_cnt[4 + cls], 1);
+    if (tid == 0) s_item = atomicAdd(&cls_cnt[8 + cls], 1);
     __syncthreads();
     const int item = s_item;
     if (item >= n_items) break;
@@ -672,173 +883,14 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
 
     // ---------------------------------------------------------------- orientation (A.5), first wavefront
-    if (tid < 64) {
-        const int g = 2 * d_cvRoundF(2 * s);
-        int nangle = 0;
-        if (!(H + 1 < g || W + 1 < g)) {
-            const int xm = g / 2;  // cvRound((float)g/4 * 2)
-            const float wxa = -1.f / ((float)xm * g), wxb = 1.f / ((float)(g - xm) * g);
-            const float wya = 1.f / ((float)g * xm), wyb = -1.f / ((float)g * (g - xm));
-            const float half = (float)(g - 1) / 2;
-            for (int pass = 0; pass < 2; pass++) {
-                const int kk = pass * 64 + lane;
-                bool inb = false;
-                float X = 0, Y = 0;
-                int Ar = 0;
-                if (kk < kOriSamples) {
-                    const int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
-                    const int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
-                    inb = !(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g);
-                    if (inb) {
-                        const int32_t* p = sum + (size_t)y * sw + x;
-                        const uint32_t t00 = p[0], t0m = p[xm], t0g = p[g];
-                        const uint32_t tm0 = p[(size_t)xm * sw], tmg = p[(size_t)xm * sw + g];
-                        const uint32_t tg0 = p[(size_t)g * sw], tgm = p[(size_t)g * sw + xm], tgg = p[(size_t)g * sw + g];
-                        // dx: boxes x[0,xm] (w<0) and x[xm,g] (w>0), both y[0,g]
-                        const int bxa = (int)(t00 + tgm - tg0 - t0m), bxb = (int)(t0m + tgg - tgm - t0g);
-                        double d = (double)((float)bxa * wxa);
-                        d += (double)((float)bxb * wxb);
-                        const float vx = (float)d;
-                        // dy: boxes y[0,xm] (w>0) and y[xm,g] (w<0), both x[0,g]
-                        const int bya = (int)(t00 + tmg - tm0 - t0g), byb = (int)(tm0 + tgg - tg0 - tmg);
-                        d = (double)((float)bya * wya);
-                        d += (double)((float)byb * wyb);
-                        const float vy = (float)d;
-                        const float w = c_tab.aptw[kk];
-                        X = vx * w;
-                        Y = vy * w;
-                        Ar = d_cvRoundF(d_fastAtan2(Y, X));
-                    }
-                }
-                const unsigned long long m = __ballot(inb);
-                if (inb) {
-                    const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
-                    s_X[pos] = X;
-                    s_Y[pos] = Y;
-                    s_A[pos] = Ar;
-                }
-                nangle += __popcll(m);
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        float best_mod = 0.f, best_x = 0.f, best_y = 0.f;
-        int best_i = 1 << 30;
-        {
-            // 72 windows, one pass: lane L sums window L and (lanes 0..7) window L + 64.  Samples outside a
-            // window add +0.f, which leaves a float sum bit-identical to skipping them.
-            const int i0 = lane * 5, i1 = (lane + 64) * 5;
-            float sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
-#pragma unroll 4
-            for (int j = 0; j < nangle; j++) {
-                const int A = s_A[j];
-                const float X = s_X[j], Y = s_Y[j];
-                const int d0 = abs(A - i0), d1 = abs(A - i1);
-                const bool in0 = d0 < 30 || d0 > 330, in1 = d1 < 30 || d1 > 330;
-                sx0 += in0 ? X : 0.f;
-                sy0 += in0 ? Y : 0.f;
-                sx1 += in1 ? X : 0.f;
-                sy1 += in1 ? Y : 0.f;
-            }
-            const float m0 = sx0 * sx0 + sy0 * sy0;
-            if (m0 > best_mod) {
-                best_mod = m0;
-                best_x = sx0;
-                best_y = sy0;
-                best_i = i0;
-            }
-            const float m1 = sx1 * sx1 + sy1 * sy1;
-            if (lane < 8 && m1 > best_mod) {  // i1 > i0: strictly greater only
-                best_mod = m1;
-                best_x = sx1;
-                best_y = sy1;
-                best_i = i1;
-            }
-        }
-        // first strict maximum over all windows: larger mod wins, ties go to the smaller i
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-            const float om = __shfl_xor(best_mod, d, 64), ox = __shfl_xor(best_x, d, 64),
-                        oy = __shfl_xor(best_y, d, 64);
-            const int oi = __shfl_xor(best_i, d, 64);
-            if (om > best_mod || (om == best_mod && oi < best_i)) {
-                best_mod = om;
-                best_x = ox;
-                best_y = oy;
-                best_i = oi;
-            }
-        }
-        if (!(best_mod > 0.f)) {
-            best_x = 0.f;
-            best_y = 0.f;
-        }
-        const float dd = d_fastAtan2(-best_y, best_x);
-        if (tid == 0) {
-            kpp->angle = dd;
-            s_dir = dd;
-        }
-    }
+    if (tid < 64) describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_X, s_Y, s_A, kpp, &s_dir);
     // ---------------------------------------------------------------- decimation tables (A.6.1)
     const double scale = (double)win / (kPatch + 1);
     const int iscale = d_cvRoundD(scale);
     const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
-    if (!area_fast && tid <= kPatch) {  // computeResizeAreaTab, one destination cell per thread
-        const int dxc = tid;
-        const double fsx1 = dxc * scale, fsx2 = fsx1 + scale;
-        const double cellWidth = fmin(scale, (double)win - fsx1);
-        int sx1 = d_cvCeilD(fsx1), sx2 = d_cvFloorD(fsx2);
-        sx2 = min(sx2, win - 1);
-        sx1 = min(sx1, sx2);
-        CellTab c;
-        c.sx1 = sx1;
-        c.sx2 = sx2;
-        c.has_head = (sx1 - fsx1 > 1e-3);
-        c.a_head = (float)((sx1 - fsx1) / cellWidth);
-        c.a_mid = (float)(1.0 / cellWidth);
-        c.has_tail = (fsx2 - sx2 > 1e-3);
-        c.a_tail = (float)(fmin(fmin(fsx2 - sx2, 1.), cellWidth) / cellWidth);
-        c.pad = 0;
-        s_cell[dxc] = c;
-    }
+    if (!area_fast && tid <= kPatch) describe_cell_tab(tid, win, scale, s_cell);
     __syncthreads();
-    if (!area_fast) {
-        for (int j = tid; j < win; j += NT) {
-            // the (at most two) table entries that read source pixel j, in destination order
-            PixTab t;
-            t.w_cur = 0.f;
-            t.w_next = 0.f;
-            t.end = 0;
-            bool have = false;
-#pragma unroll 1
-            for (int c = 0; c <= kPatch; c++) {
-                const CellTab ct = s_cell[c];
-                float w = 0.f;
-                bool hit = false;
-                if (ct.has_head && j == ct.sx1 - 1) {
-                    w = ct.a_head;
-                    hit = true;
-                } else if (j >= ct.sx1 && j < ct.sx2) {
-                    w = ct.a_mid;
-                    hit = true;
-                } else if (ct.has_tail && j == ct.sx2) {
-                    w = ct.a_tail;
-                    hit = true;
-                }
-                if (hit) {
-                    if (!have) {
-                        have = true;
-                        t.w_cur = w;
-                        const int last = ct.has_tail ? ct.sx2 : ct.sx2 - 1;
-                        t.end = (j == last) ? 1 : 0;
-                    } else {
-                        t.w_next = w;
-                    }
-                }
-            }
-            s_pix[j] = t;
-        }
-    }
+    if (!area_fast) describe_pix_tab(tid, NT, win, s_cell, s_pix);
     __syncthreads();
 
     // ---------------------------------------------------------------- descriptor window (A.6)
@@ -1069,42 +1121,263 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     }
     __syncthreads();
 
-    // gradients weighted by the Gaussian (DX into s_rowbuf[0..399], DY into [400..799])
-    float* s_DX = s_rowbuf;
-    float* s_DY = s_rowbuf + kPatch * kPatch;
-    for (int it = tid; it < kPatch * kPatch; it += NT) {
-        const int i = it / kPatch, j = it - i * kPatch;
-        const float dw = c_tab.DW[it];
-        const int p00 = s_patch[i * (kPatch + 1) + j], p01 = s_patch[i * (kPatch + 1) + j + 1];
-        const int p10 = s_patch[(i + 1) * (kPatch + 1) + j], p11 = s_patch[(i + 1) * (kPatch + 1) + j + 1];
-        s_DX[it] = (float)(p01 - p00 + p11 - p10) * dw;
-        s_DY[it] = (float)(p10 - p00 + p11 - p01) * dw;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        // lane = cell*4 + q : 25 sequential float adds per lane, the order of the reference loops
-        const int cell = lane >> 2, q = lane & 3;
-        const int ci = cell >> 2, cj = cell & 3;
-        float acc = 0.f;
-        for (int y = ci * 5; y < ci * 5 + 5; y++)
-            for (int x = cj * 5; x < cj * 5 + 5; x++) {
-                const float tx = s_DX[y * kPatch + x], ty = s_DY[y * kPatch + x];
-                const float v = q == 0 ? tx : (q == 1 ? ty : (q == 2 ? fabsf(tx) : fabsf(ty)));
-                acc += v;
-            }
-        s_vec[lane] = acc;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double square_mag = 0;
-        for (int kk = 0; kk < 64; kk++) {
-            const float v = s_vec[kk];
-            square_mag += (double)(v * v);
-        }
-        const float nscale = (float)(1. / (sqrt(square_mag) + (double)FLT_EPSILON));
-        desc_base[((size_t)frame * cap + k) * 64 + lane] = s_vec[lane] * nscale;
-    }
+    describe_patch_to_vec(tid, NT, s_patch, s_rowbuf, s_vec, desc_base + ((size_t)frame * cap + k) * 64);
     }  // work queue
+}
+
+// ------------------------------------------------------------------------------------------------
+// a6, main path: descriptor window sampled in compact 2-D blocks.
+//
+// The reference walks every window row with pixel_x += cos_dir in double (A.6).  start_x and cos_dir are
+// floats, so whenever |cos_dir|, |sin_dir| and the row start are 0 or >= 2^-17 (and < 7000) every partial
+// sum start + j*step is a multiple of 2^-40 below 2^13: it fits a double exactly, the sequential
+// accumulation never rounds, and pixel(i, j) = fma(j, step, start_i) is the SAME double.  That frees the lane
+// mapping: a wavefront samples RB rows x 64/RB consecutive columns per load instruction, so the 64 bilinear
+// footprints of one gather touch ~10 cache lines instead of ~45 (row-per-lane walk).  Samples go to a u8
+// strip in LDS; the INTER_AREA row pass is one (row, destination cell) per lane, the vertical pass streams
+// strip by strip through 21 lanes, so the window never exists outside LDS.  A keypoint that fails the
+// exactness test (e.g. an orientation of exactly 90 degrees: cos = -4.4e-8) goes to list 4 and is described by
+// the sequential walk of k_describe.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool exact_step(float v) { return v == 0.f || fabsf(v) >= 0x1p-17f; }
+__device__ __forceinline__ bool exact_start(float v) { return (v == 0.f || fabsf(v) >= 0x1p-17f) && fabsf(v) < 7000.f; }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+// bilinear sample from the two 16-bit tap pairs (row iy: t0 = p00 | p01 << 8, row iy + 1: t1), rounded to u8;
+// the reference's expression order: p00*(1-a)*(1-b) + p01*a*(1-b) + p10*(1-a)*b + p11*a*b
+__device__ __forceinline__ int bilinear_u8(uint32_t t0, uint32_t t1, float a, float b) {
+    const f32x2 wx = {1.f - a, a};
+    const float omb = 1.f - b;
+    f32x2 r0 = {(float)(t0 & 255u), (float)(t0 >> 8)};
+    f32x2 r1 = {(float)(t1 & 255u), (float)(t1 >> 8)};
+    r0 = r0 * wx;
+    r1 = r1 * wx;
+    r0 = r0 * omb;
+    r1 = r1 * b;
+    float v = r0.x + r0.y;
+    v = v + r1.x;
+    v = v + r1.y;
+    return (int)(uint8_t)d_cvRoundF(v);
+}
+
+// U samples of one lane at columns j0 + u * CB, all inside the window.  (px0, py0) is the exact position of
+// column j0, (dxs, dys) the exact step of CB columns.  Coordinates are linear in the column, so the batch lies
+// in the frame interior iff its first and last sample do; then the 2 * U tap loads go out back to back.
+template <int U, int CB>
+__device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, int W, int ncols1, int nrows1, double px0,
+                                             double py0, double dxs, double dys, lds_u8* wdst) {
+    const double pxl = px0 + (double)(U - 1) * dxs, pyl = py0 + (double)(U - 1) * dys;
+    const int ix0 = (int)floor(px0), iy0 = (int)floor(py0), ixl = (int)floor(pxl), iyl = (int)floor(pyl);
+    const bool ok = (unsigned)ix0 < (unsigned)ncols1 && (unsigned)iy0 < (unsigned)nrows1 &&
+                    (unsigned)ixl < (unsigned)ncols1 && (unsigned)iyl < (unsigned)nrows1;
+    if (__ballot(!ok) == 0ull) {
+        float a[U], b[U];
+        uint16_t t0[U], t1[U];
+        double px = px0, py = py0;
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const double flx = floor(px), fly = floor(py);
+            a[u] = (float)(px - flx);
+            b[u] = (float)(py - fly);
+            const uint32_t off = (uint32_t)__mul24((int)fly, W) + (uint32_t)(int)flx;
+            __builtin_memcpy(&t0[u], img + off, 2);  // the two taps of an image row in ONE unaligned 16-bit load
+            __builtin_memcpy(&t1[u], img + (uint32_t)(off + (uint32_t)W), 2);
+            px += dxs;
+            py += dys;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) wdst[u * CB] = (uint8_t)bilinear_u8(t0[u], t1[u], a[u], b[u]);
+    } else {  // frame border: the generic sampler (clamped nearest pixel outside the interior)
+        double px = px0, py = py0;
+#pragma unroll 1
+        for (int u = 0; u < U; u++) {
+            wdst[u * CB] = (uint8_t)sample_pixel(img, W, ncols1, nrows1, px, py);
+            px += dxs;
+            py += dys;
+        }
+    }
+}
+
+template <int WHI, int NW, int RB>
+__global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
+                                                            const int32_t* __restrict__ sum_base, size_t sum_stride, int H,
+                                                            int W, vo_keypoint* __restrict__ kp_base,
+                                                            float* __restrict__ desc_base, int cap,
+                                                            const int* __restrict__ list, int* __restrict__ cls_cnt, int cls,
+                                                            int* __restrict__ seq_list, int force_seq) {
+    constexpr int NT = NW * 64;
+    constexpr int CB = 64 / RB;                    // columns of one gather
+    constexpr int RS = NW * RB;                    // rows of one strip
+    constexpr int kPitch = ((WHI + 3) & ~3) + 4;   // bytes per strip row: an odd number of dwords
+    static_assert(((kPitch / 4) & 1) == 1, "strip pitch must be an odd number of dwords");
+    __shared__ float s_X[kOriSamples + 15], s_Y[kOriSamples + 15];
+    __shared__ int s_A[kOriSamples + 15];
+    __shared__ CellTab s_cell[kPatch + 1];
+    __shared__ PixTab s_pix[WHI];
+    __shared__ __attribute__((aligned(16))) uint8_t s_win[NW * RB * kPitch];
+    __shared__ float s_rowv[2 * RS * (kPatch + 1)];  // row-pass results of a strip (float, or int for integer scales)
+    __shared__ float s_grad[2 * kPatch * kPatch];
+    __shared__ uint8_t s_patch[(kPatch + 1) * (kPatch + 1) + 7];
+    __shared__ float s_vec[64];
+    __shared__ float s_dir;
+    __shared__ int s_item;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int r = lane / CB, c = lane - r * CB;
+    const int sw = W + 1;
+    const int n_items = cls_cnt[cls];
+    for (;;) {
+        __syncthreads();  // previous keypoint's LDS is no longer read
+        if (tid == 0) s_item = atomicAdd(&cls_cnt[8 + cls], 1);
+        __syncthreads();
+        const int item = s_item;
+        if (item >= n_items) break;
+        const int code = list[item];
+        const int frame = code / cap, k = code - frame * cap;
+        vo_keypoint* kpp = kp_base + (size_t)frame * cap + k;
+        const float size = kpp->size;
+        const float cx = kpp->x, cy = kpp->y;
+        const float s = size * 1.2f / 9.0f;
+        const int win = (int)((kPatch + 1) * s);
+        const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
+        const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
+
+        if (tid < 64) describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_X, s_Y, s_A, kpp, &s_dir);
+        const double scale = (double)win / (kPatch + 1);
+        const int iscale = d_cvRoundD(scale);
+        const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
+        if (!area_fast && tid <= kPatch) describe_cell_tab(tid, win, scale, s_cell);
+        __syncthreads();
+        if (!area_fast) describe_pix_tab(tid, NT, win, s_cell, s_pix);
+        __syncthreads();
+
+        const float descriptor_dir = s_dir;
+        const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
+        const float sin_dir = -(float)sin((double)dir);
+        const float cos_dir = (float)cos((double)dir);
+        const float win_offset = -(float)(win - 1) / 2;
+        float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
+        float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
+        const int ncols1 = W - 1, nrows1 = H - 1;
+        const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
+        const double dxs = (double)CB * dcos, dys = (double)CB * ndsin;  // exact: CB is a power of two
+        bool bad = force_seq != 0 || !(exact_step(cos_dir) && exact_step(sin_dir));
+
+        // row starts are a sequential FLOAT accumulation: every lane walks to its own row
+        const int row0 = wave * RB + r;
+#pragma unroll 1
+        for (int q = 0; q < row0; q++) {
+            start_x += sin_dir;
+            start_y += cos_dir;
+        }
+        lds_u8* wbase = (lds_u8*)s_win + wave * (RB * kPitch);
+        int* s_rowi = reinterpret_cast<int*>(s_rowv);
+        // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane)
+        float vacc = 0.f;
+        int viacc = 0, dy = 0, left = iscale;
+
+        for (int i0 = 0, sidx = 0; i0 < win; i0 += RS, sidx ^= 1) {
+            const int wrow0 = i0 + wave * RB;  // first row of this wavefront's part of the strip
+            if (wrow0 < win) {
+                const bool rowact = wrow0 + r < win;
+                bad = bad || (rowact && !(exact_start(start_x) && exact_start(start_y)));
+                // idle rows of the window's last strip repeat the wavefront's first row (always inside the window), so
+                // that every lane computes a valid sample and no load needs a guard
+                const float sx0 = __shfl(start_x, c, 64), sy0 = __shfl(start_y, c, 64);
+                const double sxd = (double)(rowact ? start_x : sx0), syd = (double)(rowact ? start_y : sy0);
+                lds_u8* wrow = wbase + r * kPitch;
+                int jb = 0;
+#define VO_BATCH(UU)                                                                                                  \
+    {                                                                                                                 \
+        const double jd = (double)(jb + c);                                                                           \
+        sample_batch<UU, CB>(img, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
+                             dys, wrow + jb + c);                                                                     \
+        jb += UU * CB;                                                                                                \
+    }
+                while (jb + 8 * CB <= win) VO_BATCH(8)
+                if (jb + 4 * CB <= win) VO_BATCH(4)
+                if (jb + 2 * CB <= win) VO_BATCH(2)
+                if (jb + CB <= win) VO_BATCH(1)
+#undef VO_BATCH
+                if (jb < win) {  // last, partial group of columns: lanes past the window repeat its last column
+                    const int jc = min(jb + c, win - 1);
+                    const double jd = (double)jc;
+                    sample_batch<1, CB>(img, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs,
+                                        dys, wrow + jc);
+                }
+                wave_sync_lds();
+                // INTER_AREA row pass: one (row, destination cell) per lane, the cell's pixels in table order
+                const int nrw = min(RB, win - wrow0);
+                for (int it = lane; it < nrw * (kPatch + 1); it += 64) {
+                    const int rr = it / (kPatch + 1), cell = it - rr * (kPatch + 1);
+                    const lds_u8* p = wbase + rr * kPitch;
+                    const int o = (sidx * RS + wave * RB + rr) * (kPatch + 1) + cell;
+                    if (area_fast) {
+                        int tot = 0;
+                        for (int q = cell * iscale; q < (cell + 1) * iscale; q++) tot += p[q];
+                        s_rowi[o] = tot;
+                    } else {
+                        const CellTab ct = s_cell[cell];
+                        float acc = 0.f;
+                        if (ct.has_head) acc += (float)p[ct.sx1 - 1] * ct.a_head;
+                        for (int q = ct.sx1; q < ct.sx2; q++) acc += (float)p[q] * ct.a_mid;
+                        if (ct.has_tail) acc += (float)p[ct.sx2] * ct.a_tail;
+                        s_rowv[o] = acc;
+                    }
+                }
+            }
+            if (NW > 1)
+                __syncthreads();  // strip complete (the other buffer half is free: its fold ended before this barrier)
+            else
+                wave_sync_lds();
+            if (tid <= kPatch) {
+                const int nrows = min(RS, win - i0);
+                const int ob = sidx * RS * (kPatch + 1) + tid;
+                if (area_fast) {
+                    for (int q = 0; q < nrows; q++) {
+                        viacc += s_rowi[ob + q * (kPatch + 1)];
+                        if (--left == 0) {
+                            int out;
+                            if (iscale == 1)
+                                out = viacc;
+                            else if (iscale == 2)
+                                out = (viacc + 2) >> 2;
+                            else
+                                out = saturate_u8(d_cvRoundF((float)viacc * (1.f / (float)(iscale * iscale))));
+                            s_patch[dy * (kPatch + 1) + tid] = (uint8_t)out;
+                            dy++;
+                            viacc = 0;
+                            left = iscale;
+                        }
+                    }
+                } else {
+                    for (int q = 0; q < nrows; q++) {
+                        const PixTab t = s_pix[i0 + q];
+                        const float val = s_rowv[ob + q * (kPatch + 1)];
+                        vacc += t.w_cur * val;
+                        if (t.end) {
+                            s_patch[dy * (kPatch + 1) + tid] = (uint8_t)saturate_u8(d_cvRoundF(vacc));
+                            dy++;
+                            vacc = t.w_next * val;
+                        }
+                    }
+                }
+            }
+#pragma unroll 1
+            for (int q = 0; q < RS; q++) {  // this lane's row of the next strip
+                start_x += sin_dir;
+                start_y += cos_dir;
+            }
+        }
+        if (__syncthreads_or(bad ? 1 : 0)) {
+            // coordinates are not exactly representable in closed form: sequential walk (k_describe, list 4)
+            if (tid == 0) seq_list[atomicAdd(&cls_cnt[4], 1)] = code;
+            continue;
+        }
+        describe_patch_to_vec(tid, NT, s_patch, s_grad, s_vec, desc_base + ((size_t)frame * cap + k) * 64);
+    }
 }
 
 // window class of every keypoint -> per-class work lists (order inside a list is irrelevant)
@@ -1172,15 +1445,19 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             const size_t ls = (size_t)fs.F * fs.cap;
             hipLaunchKernelGGL(k_classify, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt,
                                fs.cls_list, ls, fs.cls_cnt);
-#define LAUNCH_DESC(LO, HI, NT, CLS, GRID)                                                                         \
-    hipLaunchKernelGGL((k_describe<LO, HI, NT>), dim3(GRID), dim3(NT), 0, ctx->stream, fs.img, fs.img_stride(), fs.sum, \
-                       fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, CLS)
+#define LAUNCH_TILED(HI, NW, RB, CLS, GRID)                                                                           \
+    hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img, fs.img_stride(), \
+                       fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, \
+                       CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe)
             // heaviest class first so that its long keypoints overlap the many short ones that follow
-            LAUNCH_DESC(kMidWin, kBigWin, 256, 3, 256);
-            LAUNCH_DESC(kSmallWin, kMidWin, 256, 2, 512);
-            LAUNCH_DESC(64, kSmallWin, 64, 1, 2048);
-            LAUNCH_DESC(0, 64, 64, 0, 2560);
-#undef LAUNCH_DESC
+            LAUNCH_TILED(kBigWin, 4, 8, 3, 768);
+            LAUNCH_TILED(kMidWin, 4, 8, 2, 1024);
+            LAUNCH_TILED(kSmallWin, 1, 8, 1, 4096);
+            LAUNCH_TILED(64, 1, 8, 0, 4096);
+#undef LAUNCH_TILED
+            // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
+            hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.sum,
+                               fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4);
             VO_HIP(hipGetLastError());
         }
     }

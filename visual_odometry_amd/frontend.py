@@ -239,6 +239,10 @@ class Context:
         return X[:, : m.value].copy()
 
     # ---- profiling
+    def debug_set(self, key, value):
+        """Test hooks (vo_debug_set): key 0 = force the sequential descriptor-window walk."""
+        self._chk(self.lib.vo_debug_set(self._h, int(key), int(value)))
+
     def profile_enable(self, on=True):
         self._chk(self.lib.vo_profile_enable(self._h, int(on)))
 
