@@ -140,6 +140,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.img, (size_t)F * H * W + 256));  // tile staging may read up to 111 bytes past a row end
     VO_TRY(dalloc(fs.sum, (size_t)F * (H + 1) * (W + 1) + 64));
     VO_TRY(dalloc(fs.colsum, (size_t)F * nbands * W));
+    VO_TRY(dalloc(fs.quad, (size_t)F * H * W + 64));
     VO_TRY(dalloc(fs.kp_raw, (size_t)F * cap));
     VO_TRY(dalloc(fs.kp, (size_t)F * cap));
     VO_TRY(dalloc(fs.rank, (size_t)F * cap));
@@ -158,6 +159,7 @@ void vo_frameset_free(FrameSet& fs) {
     dfree(fs.img);
     dfree(fs.sum);
     dfree(fs.colsum);
+    dfree(fs.quad);
     dfree(fs.kp_raw);
     dfree(fs.kp);
     dfree(fs.rank);

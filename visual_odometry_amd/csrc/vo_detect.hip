@@ -1125,6 +1125,21 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     }  // work queue
 }
 
+// Bilinear footprint image for the descriptor sampler: one aligned 32-bit word per pixel holds the 2x2 taps
+// (p00 | p01 << 8 | p10 << 16 | p11 << 24), so a sample costs ONE gather instead of two unaligned 16-bit ones
+// (tools/microbench/gather_bench.hip: 2.2-2.5x the gather rate of the u8 image on gfx950).  The last row and
+// column repeat the edge pixel; the sampler only reads footprints with ix < W-1, iy < H-1.
+__global__ __launch_bounds__(256) void k_quads(const uint8_t* __restrict__ img_base, size_t img_stride, int H, int W,
+                                               uint32_t* __restrict__ quad_base) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, frame = blockIdx.z;
+    if (x >= W) return;
+    const uint8_t* img = img_base + (size_t)frame * img_stride;
+    const int x1 = min(x + 1, W - 1), y1 = min(y + 1, H - 1);
+    const uint32_t p00 = img[(size_t)y * W + x], p01 = img[(size_t)y * W + x1];
+    const uint32_t p10 = img[(size_t)y1 * W + x], p11 = img[(size_t)y1 * W + x1];
+    quad_base[(size_t)frame * img_stride + (size_t)y * W + x] = p00 | (p01 << 8) | (p10 << 16) | (p11 << 24);
+}
+
 // ------------------------------------------------------------------------------------------------
 // a6, main path: descriptor window sampled in compact 2-D blocks.
 //
@@ -1144,13 +1159,13 @@ __device__ __forceinline__ bool exact_start(float v) { return (v == 0.f || fabsf
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-// bilinear sample from the two 16-bit tap pairs (row iy: t0 = p00 | p01 << 8, row iy + 1: t1), rounded to u8;
+// bilinear sample from one footprint word (k_quads), rounded to u8;
 // the reference's expression order: p00*(1-a)*(1-b) + p01*a*(1-b) + p10*(1-a)*b + p11*a*b
-__device__ __forceinline__ int bilinear_u8(uint32_t t0, uint32_t t1, float a, float b) {
+__device__ __forceinline__ int bilinear_u8(uint32_t q, float a, float b) {
     const f32x2 wx = {1.f - a, a};
     const float omb = 1.f - b;
-    f32x2 r0 = {(float)(t0 & 255u), (float)(t0 >> 8)};
-    f32x2 r1 = {(float)(t1 & 255u), (float)(t1 >> 8)};
+    f32x2 r0 = {(float)(q & 255u), (float)((q >> 8) & 255u)};
+    f32x2 r1 = {(float)((q >> 16) & 255u), (float)(q >> 24)};
     r0 = r0 * wx;
     r1 = r1 * wx;
     r0 = r0 * omb;
@@ -1165,29 +1180,28 @@ __device__ __forceinline__ int bilinear_u8(uint32_t t0, uint32_t t1, float a, fl
 // column j0, (dxs, dys) the exact step of CB columns.  Coordinates are linear in the column, so the batch lies
 // in the frame interior iff its first and last sample do; then the 2 * U tap loads go out back to back.
 template <int U, int CB>
-__device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, int W, int ncols1, int nrows1, double px0,
-                                             double py0, double dxs, double dys, lds_u8* wdst) {
+__device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, const uint32_t* __restrict__ quad, int W,
+                                             int ncols1, int nrows1, double px0, double py0, double dxs, double dys,
+                                             lds_u8* wdst) {
     const double pxl = px0 + (double)(U - 1) * dxs, pyl = py0 + (double)(U - 1) * dys;
     const int ix0 = (int)floor(px0), iy0 = (int)floor(py0), ixl = (int)floor(pxl), iyl = (int)floor(pyl);
     const bool ok = (unsigned)ix0 < (unsigned)ncols1 && (unsigned)iy0 < (unsigned)nrows1 &&
                     (unsigned)ixl < (unsigned)ncols1 && (unsigned)iyl < (unsigned)nrows1;
     if (__ballot(!ok) == 0ull) {
         float a[U], b[U];
-        uint16_t t0[U], t1[U];
+        uint32_t q[U];
         double px = px0, py = py0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
             const double flx = floor(px), fly = floor(py);
             a[u] = (float)(px - flx);
             b[u] = (float)(py - fly);
-            const uint32_t off = (uint32_t)__mul24((int)fly, W) + (uint32_t)(int)flx;
-            __builtin_memcpy(&t0[u], img + off, 2);  // the two taps of an image row in ONE unaligned 16-bit load
-            __builtin_memcpy(&t1[u], img + (uint32_t)(off + (uint32_t)W), 2);
+            q[u] = quad[(uint32_t)__mul24((int)fly, W) + (uint32_t)(int)flx];
             px += dxs;
             py += dys;
         }
 #pragma unroll
-        for (int u = 0; u < U; u++) wdst[u * CB] = (uint8_t)bilinear_u8(t0[u], t1[u], a[u], b[u]);
+        for (int u = 0; u < U; u++) wdst[u * CB] = (uint8_t)bilinear_u8(q[u], a[u], b[u]);
     } else {  // frame border: the generic sampler (clamped nearest pixel outside the interior)
         double px = px0, py = py0;
 #pragma unroll 1
@@ -1201,6 +1215,7 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, in
 
 template <int WHI, int NW, int RB>
 __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
+                                                            const uint32_t* __restrict__ quad_base,
                                                             const int32_t* __restrict__ sum_base, size_t sum_stride, int H,
                                                             int W, vo_keypoint* __restrict__ kp_base,
                                                             float* __restrict__ desc_base, int cap,
@@ -1242,6 +1257,7 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
         const float s = size * 1.2f / 9.0f;
         const int win = (int)((kPatch + 1) * s);
         const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
+        const uint32_t* __restrict__ quad = quad_base + (size_t)frame * img_stride;
         const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
 
         if (tid < 64) describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_X, s_Y, s_A, kpp, &s_dir);
@@ -1292,7 +1308,7 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
 #define VO_BATCH(UU)                                                                                                  \
     {                                                                                                                 \
         const double jd = (double)(jb + c);                                                                           \
-        sample_batch<UU, CB>(img, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
+        sample_batch<UU, CB>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
                              dys, wrow + jb + c);                                                                     \
         jb += UU * CB;                                                                                                \
     }
@@ -1304,7 +1320,7 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
                 if (jb < win) {  // last, partial group of columns: lanes past the window repeat its last column
                     const int jc = min(jb + c, win - 1);
                     const double jd = (double)jc;
-                    sample_batch<1, CB>(img, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs,
+                    sample_batch<1, CB>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs,
                                         dys, wrow + jc);
                 }
                 wave_sync_lds();
@@ -1445,9 +1461,11 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             const size_t ls = (size_t)fs.F * fs.cap;
             hipLaunchKernelGGL(k_classify, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt,
                                fs.cls_list, ls, fs.cls_cnt);
+            hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                               fs.H, fs.W, fs.quad);
 #define LAUNCH_TILED(HI, NW, RB, CLS, GRID)                                                                           \
     hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img, fs.img_stride(), \
-                       fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, \
+                       fs.quad, fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, \
                        CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe)
             // heaviest class first so that its long keypoints overlap the many short ones that follow
             LAUNCH_TILED(kBigWin, 4, 8, 3, 768);
