@@ -1193,10 +1193,10 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
         double px = px0, py = py0;
 #pragma unroll
         for (int u = 0; u < U; u++) {
-            const double flx = floor(px), fly = floor(py);
-            a[u] = (float)(px - flx);
-            b[u] = (float)(py - fly);
-            q[u] = quad[(uint32_t)__mul24((int)fly, W) + (uint32_t)(int)flx];
+            // interior samples have px, py >= 0: truncation is floor, and fract(p) = p - floor(p) exactly
+            a[u] = (float)__builtin_amdgcn_fract(px);
+            b[u] = (float)__builtin_amdgcn_fract(py);
+            q[u] = quad[(uint32_t)__mul24((int)py, W) + (uint32_t)(int)px];
             px += dxs;
             py += dys;
         }
@@ -1232,6 +1232,7 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
     __shared__ PixTab s_pix[WHI];
     __shared__ __attribute__((aligned(16))) uint8_t s_win[NW * RB * kPitch];
     __shared__ float s_rowv[2 * RS * (kPatch + 1)];  // row-pass results of a strip (float, or int for integer scales)
+    __shared__ float s_sx[WHI], s_sy[WHI];           // start of every window row (sequential float accumulation)
     __shared__ float s_grad[2 * kPatch * kPatch];
     __shared__ uint8_t s_patch[(kPatch + 1) * (kPatch + 1) + 7];
     __shared__ float s_vec[64];
@@ -1266,28 +1267,30 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
         const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
         if (!area_fast && tid <= kPatch) describe_cell_tab(tid, win, scale, s_cell);
         __syncthreads();
-        if (!area_fast) describe_pix_tab(tid, NT, win, s_cell, s_pix);
-        __syncthreads();
-
         const float descriptor_dir = s_dir;
         const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
         const float sin_dir = -(float)sin((double)dir);
         const float cos_dir = (float)cos((double)dir);
         const float win_offset = -(float)(win - 1) / 2;
-        float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
-        float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
         const int ncols1 = W - 1, nrows1 = H - 1;
         const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
         const double dxs = (double)CB * dcos, dys = (double)CB * ndsin;  // exact: CB is a power of two
         bool bad = force_seq != 0 || !(exact_step(cos_dir) && exact_step(sin_dir));
-
-        // row starts are a sequential FLOAT accumulation: every lane walks to its own row
-        const int row0 = wave * RB + r;
-#pragma unroll 1
-        for (int q = 0; q < row0; q++) {
-            start_x += sin_dir;
-            start_y += cos_dir;
+        if (tid >= NT - 2) {
+            // row starts are a sequential FLOAT accumulation (start_x += sin_dir): two lanes walk it once per keypoint
+            const bool isy = tid == NT - 1;
+            float v = isy ? cy - win_offset * sin_dir + win_offset * cos_dir : cx + win_offset * cos_dir + win_offset * sin_dir;
+            const float inc = isy ? cos_dir : sin_dir;
+            float* tab = isy ? s_sy : s_sx;
+#pragma unroll 4
+            for (int q = 0; q < win; q++) {
+                tab[q] = v;
+                v += inc;
+            }
         }
+        if (!area_fast) describe_pix_tab(tid, NT, win, s_cell, s_pix);
+        __syncthreads();
+
         lds_u8* wbase = (lds_u8*)s_win + wave * (RB * kPitch);
         int* s_rowi = reinterpret_cast<int*>(s_rowv);
         // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane)
@@ -1297,12 +1300,12 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
         for (int i0 = 0, sidx = 0; i0 < win; i0 += RS, sidx ^= 1) {
             const int wrow0 = i0 + wave * RB;  // first row of this wavefront's part of the strip
             if (wrow0 < win) {
-                const bool rowact = wrow0 + r < win;
-                bad = bad || (rowact && !(exact_start(start_x) && exact_start(start_y)));
                 // idle rows of the window's last strip repeat the wavefront's first row (always inside the window), so
                 // that every lane computes a valid sample and no load needs a guard
-                const float sx0 = __shfl(start_x, c, 64), sy0 = __shfl(start_y, c, 64);
-                const double sxd = (double)(rowact ? start_x : sx0), syd = (double)(rowact ? start_y : sy0);
+                const int irow = wrow0 + r < win ? wrow0 + r : wrow0;
+                const float start_x = s_sx[irow], start_y = s_sy[irow];
+                bad = bad || !(exact_start(start_x) && exact_start(start_y));
+                const double sxd = (double)start_x, syd = (double)start_y;
                 lds_u8* wrow = wbase + r * kPitch;
                 int jb = 0;
 #define VO_BATCH(UU)                                                                                                  \
@@ -1380,11 +1383,6 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
                         }
                     }
                 }
-            }
-#pragma unroll 1
-            for (int q = 0; q < RS; q++) {  // this lane's row of the next strip
-                start_x += sin_dir;
-                start_y += cos_dir;
             }
         }
         if (__syncthreads_or(bad ? 1 : 0)) {
