@@ -62,6 +62,14 @@ void vo_build_detect_tables(DetectTables& t, int) {
                 L.ydx[k] = e27[k];
                 L.xdy[k] = e27[k];
             }
+            {   // the integer form used for compile-time box corners (box_geom) must agree with the float rounding
+                const int v[10] = {R(0), R(1), R(2), R(3), R(4), R(5), R(6), R(7), R(8), R(9)};
+                for (int k = 0; k < 10; k++)
+                    if (v[k] != (2 * L.size * k + 9) / 18) {
+                        std::fprintf(stderr, "vo_mi355x: box corner table mismatch (size %d, v %d)\n", L.size, k);
+                        std::abort();
+                    }
+            }
             const float wsgn[3] = {1, -2, 1};
             for (int k = 0; k < 3; k++) {
                 // w = src[4] / ((float)(dx2-dx1) * (dy2-dy1))
@@ -126,55 +134,73 @@ __device__ __forceinline__ float d_fastAtan2(float y, float x) {
     return a;
 }
 
-// Dx, Dy, Dxy of one layer at the sample whose box origin is `org` (pointer into the integral
-// image, row pitch sw).  Integer box sums are exact in any association (mod 2^32); the float
-// multiply and the double accumulation follow calcHaarPattern.
-__device__ __forceinline__ void hessian_boxes(const LayerTab& L, const int32_t* __restrict__ org, int sw, float& dx,
-                                              float& dy, float& dxy) {
+// Box corners of one layer: cvRound(size/9 * v).  size*v/9 is never within 1/18 of a tie, so the
+// integer form below equals the float rounding of the reference; vo_build_detect_tables checks that.
+struct BoxGeom {
+    int ex[4];   // R(0), R(3), R(6), R(9): x edges of Dxx boxes = y edges of Dyy boxes
+    int e27[2];  // R(2), R(7)
+    int c[4];    // R(1), R(4), R(5), R(8): Dxy corners
+};
+constexpr int box_round(int size, int v) { return (2 * size * v + 9) / 18; }
+constexpr BoxGeom box_geom(int size) {
+    return BoxGeom{{box_round(size, 0), box_round(size, 3), box_round(size, 6), box_round(size, 9)},
+                   {box_round(size, 2), box_round(size, 7)},
+                   {box_round(size, 1), box_round(size, 4), box_round(size, 5), box_round(size, 8)}};
+}
+
+// Dx, Dy, Dxy of one layer at one sample.  tap(y, x) returns the integral image at offset (y, x) from the
+// sample's box origin.  Integer box sums are exact in any association (mod 2^32); the float multiply and the
+// double accumulation follow calcHaarPattern.
+template <class Tap>
+__device__ __forceinline__ void hessian_boxes_t(const BoxGeom& G, const float* __restrict__ w, const Tap& tap, float& dx,
+                                                float& dy, float& dxy) {
     {
-        const int32_t* r0 = org + L.ydx[0] * sw;
-        const int32_t* r1 = org + L.ydx[1] * sw;
-        uint32_t v0 = (uint32_t)r1[L.xdx[0]] - (uint32_t)r0[L.xdx[0]];
-        uint32_t v1 = (uint32_t)r1[L.xdx[1]] - (uint32_t)r0[L.xdx[1]];
-        uint32_t v2 = (uint32_t)r1[L.xdx[2]] - (uint32_t)r0[L.xdx[2]];
-        uint32_t v3 = (uint32_t)r1[L.xdx[3]] - (uint32_t)r0[L.xdx[3]];
-        double d = (double)((float)(int32_t)(v1 - v0) * L.w[0]);
-        d += (double)((float)(int32_t)(v2 - v1) * L.w[1]);
-        d += (double)((float)(int32_t)(v3 - v2) * L.w[2]);
+        const int y0 = G.e27[0], y1 = G.e27[1];
+        uint32_t v0 = tap(y1, G.ex[0]) - tap(y0, G.ex[0]);
+        uint32_t v1 = tap(y1, G.ex[1]) - tap(y0, G.ex[1]);
+        uint32_t v2 = tap(y1, G.ex[2]) - tap(y0, G.ex[2]);
+        uint32_t v3 = tap(y1, G.ex[3]) - tap(y0, G.ex[3]);
+        double d = (double)((float)(int32_t)(v1 - v0) * w[0]);
+        d += (double)((float)(int32_t)(v2 - v1) * w[1]);
+        d += (double)((float)(int32_t)(v3 - v2) * w[2]);
         dx = (float)d;
     }
     {
-        const int x0 = L.xdy[0], x1 = L.xdy[1];
-        const int32_t* r0 = org + L.ydy[0] * sw;
-        const int32_t* r1 = org + L.ydy[1] * sw;
-        const int32_t* r2 = org + L.ydy[2] * sw;
-        const int32_t* r3 = org + L.ydy[3] * sw;
-        uint32_t h0 = (uint32_t)r0[x1] - (uint32_t)r0[x0];
-        uint32_t h1 = (uint32_t)r1[x1] - (uint32_t)r1[x0];
-        uint32_t h2 = (uint32_t)r2[x1] - (uint32_t)r2[x0];
-        uint32_t h3 = (uint32_t)r3[x1] - (uint32_t)r3[x0];
-        double d = (double)((float)(int32_t)(h1 - h0) * L.w[3]);
-        d += (double)((float)(int32_t)(h2 - h1) * L.w[4]);
-        d += (double)((float)(int32_t)(h3 - h2) * L.w[5]);
+        const int x0 = G.e27[0], x1 = G.e27[1];
+        uint32_t h0 = tap(G.ex[0], x1) - tap(G.ex[0], x0);
+        uint32_t h1 = tap(G.ex[1], x1) - tap(G.ex[1], x0);
+        uint32_t h2 = tap(G.ex[2], x1) - tap(G.ex[2], x0);
+        uint32_t h3 = tap(G.ex[3], x1) - tap(G.ex[3], x0);
+        double d = (double)((float)(int32_t)(h1 - h0) * w[3]);
+        d += (double)((float)(int32_t)(h2 - h1) * w[4]);
+        d += (double)((float)(int32_t)(h3 - h2) * w[5]);
         dy = (float)d;
     }
     {
-        const int c0 = L.cxy[0], c1 = L.cxy[1], c2 = L.cxy[2], c3 = L.cxy[3];
-        const int32_t* r0 = org + c0 * sw;
-        const int32_t* r1 = org + c1 * sw;
-        const int32_t* r2 = org + c2 * sw;
-        const int32_t* r3 = org + c3 * sw;
+        const int c0 = G.c[0], c1 = G.c[1], c2 = G.c[2], c3 = G.c[3];
         // horizontal differences over [c0,c1] and [c2,c3] on the four rows
-        uint32_t a0 = (uint32_t)r0[c1] - (uint32_t)r0[c0], b0 = (uint32_t)r0[c3] - (uint32_t)r0[c2];
-        uint32_t a1 = (uint32_t)r1[c1] - (uint32_t)r1[c0], b1 = (uint32_t)r1[c3] - (uint32_t)r1[c2];
-        uint32_t a2 = (uint32_t)r2[c1] - (uint32_t)r2[c0], b2 = (uint32_t)r2[c3] - (uint32_t)r2[c2];
-        uint32_t a3 = (uint32_t)r3[c1] - (uint32_t)r3[c0], b3 = (uint32_t)r3[c3] - (uint32_t)r3[c2];
-        double d = (double)((float)(int32_t)(a1 - a0) * L.w[6]);  // x[c0,c1] y[c0,c1]
-        d += (double)((float)(int32_t)(b1 - b0) * L.w[7]);        // x[c2,c3] y[c0,c1]
-        d += (double)((float)(int32_t)(a3 - a2) * L.w[8]);        // x[c0,c1] y[c2,c3]
-        d += (double)((float)(int32_t)(b3 - b2) * L.w[9]);        // x[c2,c3] y[c2,c3]
+        uint32_t a0 = tap(c0, c1) - tap(c0, c0), b0 = tap(c0, c3) - tap(c0, c2);
+        uint32_t a1 = tap(c1, c1) - tap(c1, c0), b1 = tap(c1, c3) - tap(c1, c2);
+        uint32_t a2 = tap(c2, c1) - tap(c2, c0), b2 = tap(c2, c3) - tap(c2, c2);
+        uint32_t a3 = tap(c3, c1) - tap(c3, c0), b3 = tap(c3, c3) - tap(c3, c2);
+        double d = (double)((float)(int32_t)(a1 - a0) * w[6]);  // x[c0,c1] y[c0,c1]
+        d += (double)((float)(int32_t)(b1 - b0) * w[7]);        // x[c2,c3] y[c0,c1]
+        d += (double)((float)(int32_t)(a3 - a2) * w[8]);        // x[c0,c1] y[c2,c3]
+        d += (double)((float)(int32_t)(b3 - b2) * w[9]);        // x[c2,c3] y[c2,c3]
         dxy = (float)d;
     }
+}
+
+struct GlobalTap {  // integral image in HBM / L2, row pitch sw
+    const int32_t* __restrict__ org;
+    int sw;
+    __device__ __forceinline__ uint32_t operator()(int y, int x) const { return (uint32_t)org[y * sw + x]; }
+};
+
+__device__ __forceinline__ void hessian_boxes(const LayerTab& L, const int32_t* __restrict__ org, int sw, float& dx,
+                                              float& dy, float& dxy) {
+    const BoxGeom G{{L.xdx[0], L.xdx[1], L.xdx[2], L.xdx[3]}, {L.ydx[0], L.ydx[1]}, {L.cxy[0], L.cxy[1], L.cxy[2], L.cxy[3]}};
+    hessian_boxes_t(G, L.w, GlobalTap{org, sw}, dx, dy, dxy);
 }
 
 __device__ __forceinline__ float hessian_det(float dx, float dy, float dxy) {
@@ -481,6 +507,172 @@ __global__ __launch_bounds__(256) void k_hessian_nms(const int32_t* __restrict__
 }
 
 // ------------------------------------------------------------------------------------------------
+// a2 + a3, octaves 0 and 1: the integral-image patch under a T x T sample tile (all five layers) is staged in
+// LDS with coalesced loads, and the 32 box taps of every sample are LDS reads.  Straight from L1/L2 the taps
+// run at the texture addresser's gather rate (~4 lanes/clk/CU, tools/microbench); the patch is read once.
+// Octave O samples every 2^O-th pixel: columns are stored de-interleaved by (col mod 2^O) so that the lanes
+// of a tile row read consecutive LDS words.
+// ------------------------------------------------------------------------------------------------
+template <int O, int PP, int HALF>
+struct LdsTap {
+    const __attribute__((address_space(3))) int32_t* base;
+    __device__ __forceinline__ uint32_t operator()(int y, int x) const {
+        return (uint32_t)base[y * PP + (x & ((1 << O) - 1)) * HALF + (x >> O)];
+    }
+};
+
+template <int T, int O>
+__global__ __launch_bounds__(256) void k_hessian_nms_lds(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+                                                         int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
+                                                         FrameCounters* __restrict__ cnt, int filter_invalid) {
+    constexpr int TI = T - 2;                       // interior samples per side (the rim is the NMS halo)
+    constexpr int step = 1 << O;
+    constexpr int kSizeMax = (9 + 6 * (kLayersPerOctave - 1)) << O;
+    constexpr int kMarginMax = (kSizeMax / 2) / step;
+    constexpr int PE = (T - 1) * step + kSizeMax + 1;  // patch extent in integral-image pixels
+    constexpr int HALF = O == 0 ? 0 : (((PE + step - 1) / step - 4 + 7) / 8 * 8 + 4);  // words per column phase, = 4 mod 8
+    constexpr int PP = O == 0 ? PE : step * HALF;
+    constexpr int DP = T + 1;
+    __shared__ int32_t s_sum[PE * PP];
+    __shared__ float s_det[kLayersPerOctave][T][DP];
+    const int o = O;
+    const int frame = blockIdx.y;
+    const int b = blockIdx.x;
+    const int ty = b / tiles_x, tx = b - ty * tiles_x;
+    const int sw = W + 1;
+    const int lrows = H / step, lcols = W / step;
+    const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
+    const int tid = threadIdx.x;
+    const int i0 = ty * TI - 1, j0 = tx * TI - 1;
+    const int prow0 = (i0 - kMarginMax) * step, pcol0 = (j0 - kMarginMax) * step;
+
+    for (int e = tid; e < PE * PE; e += 256) {
+        const int pr = e / PE, pc = e - pr * PE;
+        const int gr = prow0 + pr, gc = pcol0 + pc;
+        int32_t v = 0;
+        if (gr >= 0 && gr <= H && gc >= 0 && gc <= W) v = sum[(size_t)gr * sw + gc];
+        s_sum[pr * PP + (pc & (step - 1)) * HALF + (pc >> O)] = v;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int l = 0; l < kLayersPerOctave; l++) {
+        const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
+        // box corners are compile-time constants here: every tap is a ds_read with an immediate offset
+        const int lsize = (9 + 6 * l) << O;
+        const BoxGeom G = box_geom(lsize);
+        const int lmargin = (lsize / 2) / step;
+        const bool fits = (lsize <= H && lsize <= W);
+        const int samples_i = fits ? 1 + (H - lsize) / step : 0;
+        const int samples_j = fits ? 1 + (W - lsize) / step : 0;
+        const int dm = kMarginMax - lmargin;
+        for (int s = tid; s < T * T; s += 256) {
+            const int yy = s / T, xx = s - yy * T;
+            const int oi = i0 + yy - lmargin, oj = j0 + xx - lmargin;
+            float dv = 0.f;
+            if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
+                float dx, dy, dxy;
+                const LdsTap<O, PP, HALF> tap{(const __attribute__((address_space(3))) int32_t*)s_sum + (yy + dm) * step * PP + (xx + dm)};
+                hessian_boxes_t(G, L.w, tap, dx, dy, dxy);
+                dv = hessian_det(dx, dy, dxy);
+            }
+            s_det[l][yy][xx] = dv;
+        }
+    }
+    __syncthreads();
+
+    vo_keypoint* __restrict__ kps = kp_base + (size_t)frame * cap;
+    const int lane = tid & 63;
+    for (int l = 1; l <= 3; l++) {
+        const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
+        const int size = L.size;
+        const int size_next = c_tab.layers[o * kLayersPerOctave + l + 1].size;
+        const int size_prev = c_tab.layers[o * kLayersPerOctave + l - 1].size;
+        const int margin = (size_next / 2) / step + 1;
+        for (int s = tid; s < TI * TI; s += 256) {
+            const int yy = s / TI, xx = s - yy * TI;
+            const int i = ty * TI + yy, j = tx * TI + xx;
+            bool emit = false;
+            vo_keypoint kpt;
+            if (i >= margin && i < lrows - margin && j >= margin && j < lcols - margin) {
+                const float val0 = s_det[l][yy + 1][xx + 1];
+                if (val0 > thr) {
+                    float N9[3][9];
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int q = 0; q < 9; q++) N9[a][q] = s_det[l - 1 + a][yy + q / 3][xx + q % 3];
+                    bool is_max = true;
+#pragma unroll
+                    for (int a = 0; a < 3; a++)
+#pragma unroll
+                        for (int q = 0; q < 9; q++)
+                            if (!(a == 1 && q == 4)) is_max = is_max && (val0 > N9[a][q]);
+                    if (is_max) {
+                        const int sum_i = step * (i - (size / 2) / step);
+                        const int sum_j = step * (j - (size / 2) / step);
+                        const float center_i = sum_i + (size - 1) * 0.5f;
+                        const float center_j = sum_j + (size - 1) * 0.5f;
+                        // interpolateKeypoint, Cramer's rule in float
+                        const float b0 = -(N9[1][5] - N9[1][3]) / 2;
+                        const float b1 = -(N9[1][7] - N9[1][1]) / 2;
+                        const float b2 = -(N9[2][4] - N9[0][4]) / 2;
+                        const float a00 = N9[1][3] - 2 * N9[1][4] + N9[1][5];
+                        const float a01 = (N9[1][8] - N9[1][6] - N9[1][2] + N9[1][0]) / 4;
+                        const float a02 = (N9[2][5] - N9[2][3] - N9[0][5] + N9[0][3]) / 4;
+                        const float a10 = a01;
+                        const float a11 = N9[1][1] - 2 * N9[1][4] + N9[1][7];
+                        const float a12 = (N9[2][7] - N9[2][1] - N9[0][7] + N9[0][1]) / 4;
+                        const float a20 = a02, a21 = a12;
+                        const float a22 = N9[0][4] - 2 * N9[1][4] + N9[2][4];
+                        float d = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) +
+                                  a02 * (a10 * a21 - a20 * a11);
+                        float x0 = 0, x1 = 0, x2 = 0;
+                        if (d != 0) {
+                            d = 1 / d;
+                            x0 = d * (b0 * (a11 * a22 - a12 * a21) - a01 * (b1 * a22 - a12 * b2) +
+                                      a02 * (b1 * a21 - a11 * b2));
+                            x1 = d * (a00 * (b1 * a22 - a12 * b2) - b0 * (a10 * a22 - a12 * a20) +
+                                      a02 * (a10 * b2 - b1 * a20));
+                            x2 = d * (a00 * (a11 * b2 - b1 * a21) - a01 * (a10 * b2 - b1 * a20) +
+                                      b0 * (a10 * a21 - a11 * a20));
+                        }
+                        const bool ok = (x0 != 0 || x1 != 0 || x2 != 0) && fabsf(x0) <= 1 && fabsf(x1) <= 1 &&
+                                        fabsf(x2) <= 1;
+                        if (ok) {
+                            const int ds = size - size_prev;
+                            kpt.x = center_j + x0 * step;
+                            kpt.y = center_i + x1 * step;
+                            kpt.size = (float)d_cvRoundF((float)size + x2 * ds);
+                            kpt.angle = -1.f;
+                            kpt.response = val0;
+                            kpt.octave = o;
+                            // trace at the same sample (the product path never materialises it)
+                            float dx, dy, dxy;
+                            hessian_boxes(L, sum + (size_t)((i - L.margin) * step) * sw + (j - L.margin) * step, sw,
+                                          dx, dy, dxy);
+                            const float tr = dx + dy;
+                            kpt.class_id = (tr > 0) - (tr < 0);
+                            emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W);
+                        }
+                    }
+                }
+            }
+            // wavefront-ballot compaction: one atomic per wave
+            const unsigned long long m = __ballot(emit);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&cnt[frame].n_raw, __popcll(m));
+                base = __shfl(base, 0, 64);
+                if (emit) {
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (pos < cap) kps[pos] = kpt;
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // a4: KeypointGreater rank sort.  rank[i] = #{j : kp_j > kp_i}; the order is total, so ranks
 // are a permutation and the scatter is deterministic whatever order NMS appended in.
 // ------------------------------------------------------------------------------------------------
@@ -689,30 +881,31 @@ __device__ __forceinline__ void describe_orientation(const int32_t* __restrict__
     float best_mod = 0.f, best_x = 0.f, best_y = 0.f;
     int best_i = 1 << 30;
     {
-        // 72 windows, one pass: lane L sums window L and (lanes 0..7) window L + 64.  Samples outside a
-        // window add +0.f, which leaves a float sum bit-identical to skipping them.
-        const int i0 = lane * 5, i1 = (lane + 64) * 5;
+        // 72 windows, one pass: lane L < 36 sums window L (centre i0 = 5L) and the opposite window L + 36.  One
+        // angular distance serves both: |A - i0| < 30 or > 330 is window L, 150 < |A - i0| < 210 is window L + 36.
+        // Samples outside a window add +0.f, which leaves a float sum bit-identical to skipping them.
+        const int i0 = (lane < 36 ? lane : 0) * 5, i1 = i0 + 180;
         float sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
 #pragma unroll 4
         for (int j = 0; j < nangle; j++) {
             const int A = s_A[j];
             const float X = s_X[j], Y = s_Y[j];
-            const int d0 = abs(A - i0), d1 = abs(A - i1);
-            const bool in0 = d0 < 30 || d0 > 330, in1 = d1 < 30 || d1 > 330;
+            const unsigned d0 = (unsigned)abs(A - i0);
+            const bool in0 = d0 - 30u > 300u, in1 = d0 - 151u < 59u;
             sx0 += in0 ? X : 0.f;
             sy0 += in0 ? Y : 0.f;
             sx1 += in1 ? X : 0.f;
             sy1 += in1 ? Y : 0.f;
         }
         const float m0 = sx0 * sx0 + sy0 * sy0;
-        if (m0 > best_mod) {
+        if (lane < 36 && m0 > best_mod) {
             best_mod = m0;
             best_x = sx0;
             best_y = sy0;
             best_i = i0;
         }
         const float m1 = sx1 * sx1 + sy1 * sy1;
-        if (lane < 8 && m1 > best_mod) {  // i1 > i0: strictly greater only
+        if (lane < 36 && m1 > best_mod) {  // i1 > i0: strictly greater only
             best_mod = m1;
             best_x = sx1;
             best_y = sy1;
@@ -1329,6 +1522,7 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
                 wave_sync_lds();
                 // INTER_AREA row pass: one (row, destination cell) per lane, the cell's pixels in table order
                 const int nrw = min(RB, win - wrow0);
+                const int nub = (int)scale + 1;
                 for (int it = lane; it < nrw * (kPatch + 1); it += 64) {
                     const int rr = it / (kPatch + 1), cell = it - rr * (kPatch + 1);
                     const lds_u8* p = wbase + rr * kPitch;
@@ -1339,10 +1533,24 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
                         s_rowi[o] = tot;
                     } else {
                         const CellTab ct = s_cell[cell];
+                        const int n = ct.sx2 - ct.sx1;  // full-weight pixels of this cell: at most nub, the same bound in every lane
+                        const int ph = p[max(ct.sx1 - 1, 0)], pt = p[ct.sx2];
+                        const lds_u8* pm = p + ct.sx1;
                         float acc = 0.f;
-                        if (ct.has_head) acc += (float)p[ct.sx1 - 1] * ct.a_head;
-                        for (int q = ct.sx1; q < ct.sx2; q++) acc += (float)p[q] * ct.a_mid;
-                        if (ct.has_tail) acc += (float)p[ct.sx2] * ct.a_tail;
+                        if (ct.has_head) acc += (float)ph * ct.a_head;
+                        // four byte reads in flight per step; the adds stay in pixel order, lanes past their own count keep acc
+                        for (int k0 = 0; k0 < nub; k0 += 4) {
+                            const int v0 = pm[k0], v1 = pm[k0 + 1], v2 = pm[k0 + 2], v3 = pm[k0 + 3];
+                            const float a0 = acc + (float)v0 * ct.a_mid;
+                            acc = k0 < n ? a0 : acc;
+                            const float a1 = acc + (float)v1 * ct.a_mid;
+                            acc = k0 + 1 < n ? a1 : acc;
+                            const float a2 = acc + (float)v2 * ct.a_mid;
+                            acc = k0 + 2 < n ? a2 : acc;
+                            const float a3 = acc + (float)v3 * ct.a_mid;
+                            acc = k0 + 3 < n ? a3 : acc;
+                        }
+                        if (ct.has_tail) acc += (float)pt * ct.a_tail;
                         s_rowv[o] = acc;
                     }
                 }
@@ -1376,7 +1584,7 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
                         const PixTab t = s_pix[i0 + q];
                         const float val = s_rowv[ob + q * (kPatch + 1)];
                         vacc += t.w_cur * val;
-                        if (t.end) {
+                        if (__builtin_amdgcn_readfirstlane(t.end)) {  // same row in every lane
                             s_patch[dy * (kPatch + 1) + tid] = (uint8_t)saturate_u8(d_cvRoundF(vacc));
                             dy++;
                             vacc = t.w_next * val;
@@ -1439,8 +1647,23 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
     g.tile_base[kNumOctaves] = base;
     {
         StageScope sc(ctx, ST_HESSIAN_NMS);
-        hipLaunchKernelGGL(k_hessian_nms, dim3(base, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(), g,
+        // octave 0 (75 % of the samples): integral patch staged in LDS.  Octaves 1-3: taps straight from L1/L2 (their
+        // patches are too large to stage: 129 x 129 words for a 32 x 32 tile of octave 1); launched first, so that their
+        // few long workgroups overlap the start of the octave-0 grid.
+        DetectGeom g2 = g;
+        g2.tiles_x[0] = g2.tiles_y[0] = 0;
+        int base2 = 0;
+        for (int o = 0; o < kNumOctaves; o++) {
+            g2.tile_base[o] = base2;
+            base2 += g2.tiles_x[o] * g2.tiles_y[o];
+        }
+        g2.tile_base[kNumOctaves] = base2;
+        hipLaunchKernelGGL(k_hessian_nms, dim3(base2, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(), g2,
                            ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
+        constexpr int T0 = 32;
+        const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
+        hipLaunchKernelGGL((k_hessian_nms_lds<T0, 0>), dim3(tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
+                           fs.H, fs.W, tx0, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
         VO_HIP(hipGetLastError());
     }
     {
