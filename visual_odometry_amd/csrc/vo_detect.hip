@@ -377,12 +377,14 @@ __device__ bool kp_describable(float cx, float cy, float size, int H, int W) {
     return false;
 }
 
-__global__ __launch_bounds__(256) void k_hessian_nms(const int32_t* __restrict__ sum_base, size_t sum_stride,
-                                                     DetectGeom g, float thr, vo_keypoint* __restrict__ kp_base,
-                                                     int cap, FrameCounters* __restrict__ cnt, int filter_invalid) {
-    __shared__ float s_det[kLayersPerOctave][kHY][kHP];
-    const int frame = blockIdx.y;
-    int b = blockIdx.x, o = 0;
+constexpr int kGlobalTileLds = kLayersPerOctave * kHY * kHP * 4;
+
+__device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int b, int frame,
+                                                        const int32_t* __restrict__ sum_base, size_t sum_stride,
+                                                        const DetectGeom& g, float thr, vo_keypoint* __restrict__ kp_base,
+                                                        int cap, FrameCounters* __restrict__ cnt, int filter_invalid) {
+    float (*s_det)[kHY][kHP] = reinterpret_cast<float (*)[kHY][kHP]>(smem);
+    int o = 0;
 #pragma unroll
     for (int q = 1; q < kNumOctaves; q++)
         if (b >= g.tile_base[q]) o = q;
@@ -522,22 +524,29 @@ struct LdsTap {
 };
 
 template <int T, int O>
-__global__ __launch_bounds__(256) void k_hessian_nms_lds(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
-                                                         int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
-                                                         FrameCounters* __restrict__ cnt, int filter_invalid) {
-    constexpr int TI = T - 2;                       // interior samples per side (the rim is the NMS halo)
-    constexpr int step = 1 << O;
-    constexpr int kSizeMax = (9 + 6 * (kLayersPerOctave - 1)) << O;
-    constexpr int kMarginMax = (kSizeMax / 2) / step;
-    constexpr int PE = (T - 1) * step + kSizeMax + 1;  // patch extent in integral-image pixels
-    constexpr int HALF = O == 0 ? 0 : (((PE + step - 1) / step - 4 + 7) / 8 * 8 + 4);  // words per column phase, = 4 mod 8
-    constexpr int PP = O == 0 ? PE : step * HALF;
-    constexpr int DP = T + 1;
-    __shared__ int32_t s_sum[PE * PP];
-    __shared__ float s_det[kLayersPerOctave][T][DP];
+struct LdsTileCfg {
+    static constexpr int TI = T - 2;                       // interior samples per side (the rim is the NMS halo)
+    static constexpr int step = 1 << O;
+    static constexpr int kSizeMax = (9 + 6 * (kLayersPerOctave - 1)) << O;
+    static constexpr int kMarginMax = (kSizeMax / 2) / step;
+    static constexpr int PE = (T - 1) * step + kSizeMax + 1;  // patch extent in integral-image pixels
+    static constexpr int HALF = O == 0 ? 0 : (((PE + step - 1) / step - 4 + 7) / 8 * 8 + 4);  // words per column phase, = 4 mod 8
+    static constexpr int PP = O == 0 ? PE : step * HALF;
+    static constexpr int DP = T + 1;
+    static constexpr int kSumBytes = PE * PP * 4;
+    static constexpr int kBytes = kSumBytes + kLayersPerOctave * T * DP * 4;
+};
+
+template <int T, int O>
+__device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b, int frame,
+                                                     const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+                                                     int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
+                                                     FrameCounters* __restrict__ cnt, int filter_invalid) {
+    using C = LdsTileCfg<T, O>;
+    constexpr int TI = C::TI, step = C::step, kMarginMax = C::kMarginMax, PE = C::PE, HALF = C::HALF, PP = C::PP, DP = C::DP;
+    int32_t* s_sum = reinterpret_cast<int32_t*>(smem);
+    float (*s_det)[T][DP] = reinterpret_cast<float (*)[T][DP]>(smem + C::kSumBytes);
     const int o = O;
-    const int frame = blockIdx.y;
-    const int b = blockIdx.x;
     const int ty = b / tiles_x, tx = b - ty * tiles_x;
     const int sw = W + 1;
     const int lrows = H / step, lcols = W / step;
@@ -546,12 +555,33 @@ __global__ __launch_bounds__(256) void k_hessian_nms_lds(const int32_t* __restri
     const int i0 = ty * TI - 1, j0 = tx * TI - 1;
     const int prow0 = (i0 - kMarginMax) * step, pcol0 = (j0 - kMarginMax) * step;
 
-    for (int e = tid; e < PE * PE; e += 256) {
-        const int pr = e / PE, pc = e - pr * PE;
-        const int gr = prow0 + pr, gc = pcol0 + pc;
-        int32_t v = 0;
-        if (gr >= 0 && gr <= H && gc >= 0 && gc <= W) v = sum[(size_t)gr * sw + gc];
-        s_sum[pr * PP + (pc & (step - 1)) * HALF + (pc >> O)] = v;
+    {
+        // patch rows go round the four wavefronts, 64 consecutive columns per load; RU rows (RU * KC loads) in flight
+        constexpr int RU = 4, KC = (PE + 63) / 64;
+        const int wv = tid >> 6, ln = tid & 63;
+        for (int pr0 = wv; pr0 < PE; pr0 += 4 * RU) {
+            int32_t v[RU][KC];
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int pr = pr0 + 4 * u, gr = prow0 + pr;
+                const bool rowok = pr < PE && gr >= 0 && gr <= H;
+#pragma unroll
+                for (int k = 0; k < KC; k++) {
+                    const int pc = ln + 64 * k, gc = pcol0 + pc;
+                    v[u][k] = 0;
+                    if (rowok && pc < PE && gc >= 0 && gc <= W) v[u][k] = sum[(size_t)gr * sw + gc];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < RU; u++) {
+                const int pr = pr0 + 4 * u;
+#pragma unroll
+                for (int k = 0; k < KC; k++) {
+                    const int pc = ln + 64 * k;
+                    if (pr < PE && pc < PE) s_sum[pr * PP + (pc & (step - 1)) * HALF + (pc >> O)] = v[u][k];
+                }
+            }
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -670,6 +700,34 @@ __global__ __launch_bounds__(256) void k_hessian_nms_lds(const int32_t* __restri
             }
         }
     }
+}
+
+// octave-0 tiles (LDS patch) and the few tiles of octaves >= OG (taps from L1/L2) in ONE grid, so that the long,
+// latency-bound workgroups of the coarse octaves overlap the bulk of the work
+template <int T0>
+__global__ __launch_bounds__(256) void k_hessian_nms_fused(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+                                                           int tiles_x0, int n_tiles0, DetectGeom g_rest, float thr,
+                                                           vo_keypoint* __restrict__ kp_base, int cap,
+                                                           FrameCounters* __restrict__ cnt, int filter_invalid) {
+    constexpr int kBytes = LdsTileCfg<T0, 0>::kBytes > kGlobalTileLds ? LdsTileCfg<T0, 0>::kBytes : kGlobalTileLds;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[kBytes];
+    const int b = blockIdx.x, frame = blockIdx.y;
+    // coarse tiles first in the grid: they are the long ones
+    const int n_rest = g_rest.tile_base[kNumOctaves];
+    if (b < n_rest)
+        hessian_nms_global_tile(smem, b, frame, sum_base, sum_stride, g_rest, thr, kp_base, cap, cnt, filter_invalid);
+    else
+        hessian_nms_lds_tile<T0, 0>(smem, b - n_rest, frame, sum_base, sum_stride, H, W, tiles_x0, thr, kp_base, cap, cnt,
+                                    filter_invalid);
+}
+
+template <int T, int O>
+__global__ __launch_bounds__(256) void k_hessian_nms_lds(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+                                                         int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
+                                                         FrameCounters* __restrict__ cnt, int filter_invalid) {
+    __shared__ __attribute__((aligned(16))) unsigned char smem[LdsTileCfg<T, O>::kBytes];
+    hessian_nms_lds_tile<T, O>(smem, blockIdx.x, blockIdx.y, sum_base, sum_stride, H, W, tiles_x, thr, kp_base, cap, cnt,
+                               filter_invalid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1647,23 +1705,24 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
     g.tile_base[kNumOctaves] = base;
     {
         StageScope sc(ctx, ST_HESSIAN_NMS);
-        // octave 0 (75 % of the samples): integral patch staged in LDS.  Octaves 1-3: taps straight from L1/L2 (their
-        // patches are too large to stage: 129 x 129 words for a 32 x 32 tile of octave 1); launched first, so that their
-        // few long workgroups overlap the start of the octave-0 grid.
+        // octaves 0 and 1 (94 % of the samples): integral patch staged in LDS.  Octaves 2-3: taps straight from L1/L2
+        // (a patch would be 2-4x the tile's own taps); their few long workgroups ride in the octave-0 grid.
         DetectGeom g2 = g;
-        g2.tiles_x[0] = g2.tiles_y[0] = 0;
+        g2.tiles_x[0] = g2.tiles_y[0] = g2.tiles_x[1] = g2.tiles_y[1] = 0;
         int base2 = 0;
         for (int o = 0; o < kNumOctaves; o++) {
             g2.tile_base[o] = base2;
             base2 += g2.tiles_x[o] * g2.tiles_y[o];
         }
         g2.tile_base[kNumOctaves] = base2;
-        hipLaunchKernelGGL(k_hessian_nms, dim3(base2, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(), g2,
-                           ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
-        constexpr int T0 = 32;
+        constexpr int T0 = 32, T1 = 24;
+        const int tx1 = ((fs.W >> 1) + T1 - 3) / (T1 - 2), ty1 = ((fs.H >> 1) + T1 - 3) / (T1 - 2);
+        hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1>), dim3(tx1 * ty1, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
+                           fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
         const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
-        hipLaunchKernelGGL((k_hessian_nms_lds<T0, 0>), dim3(tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
-                           fs.H, fs.W, tx0, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
+        hipLaunchKernelGGL((k_hessian_nms_fused<T0>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
+                           fs.sum_stride(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
+                           describe ? 1 : 0);
         VO_HIP(hipGetLastError());
     }
     {
