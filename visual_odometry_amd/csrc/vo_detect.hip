@@ -17,6 +17,7 @@
 // Arithmetic follows the order of operations of SURVEY.md Appendix A exactly; the file is
 // compiled with -ffp-contract=off so that every float/double operation rounds once.
 #include "vo_common.hpp"
+#include <type_traits>
 
 #include <cfloat>
 #include <cmath>
@@ -1015,7 +1016,8 @@ __device__ __forceinline__ void describe_cell_tab(int tid, int win, double scale
 }
 
 // per-source-pixel view of the same table (see PixTab)
-__device__ __forceinline__ void describe_pix_tab(int tid, int NT, int win, const CellTab* s_cell, PixTab* s_pix) {
+__device__ __forceinline__ void describe_pix_tab(int tid, int NT, int win, double scale, const CellTab* s_cell,
+                                                 PixTab* s_pix) {
     for (int j = tid; j < win; j += NT) {
         // the (at most two) table entries that read source pixel j, in destination order
         PixTab t;
@@ -1023,8 +1025,10 @@ __device__ __forceinline__ void describe_pix_tab(int tid, int NT, int win, const
         t.w_next = 0.f;
         t.end = 0;
         bool have = false;
+        // cell c reads pixels [c*scale - 1, (c+1)*scale]: only cells floor(j/scale) - 1 .. + 2 can hold pixel j
+        const int cfirst = max((int)((double)j / scale) - 1, 0), clast = min(cfirst + 3, kPatch);
 #pragma unroll 1
-        for (int c = 0; c <= kPatch; c++) {
+        for (int c = cfirst; c <= clast; c++) {
             const CellTab ct = s_cell[c];
             float w = 0.f;
             bool hit = false;
@@ -1141,7 +1145,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
     if (!area_fast && tid <= kPatch) describe_cell_tab(tid, win, scale, s_cell);
     __syncthreads();
-    if (!area_fast) describe_pix_tab(tid, NT, win, s_cell, s_pix);
+    if (!area_fast) describe_pix_tab(tid, NT, win, scale, s_cell, s_pix);
     __syncthreads();
 
     // ---------------------------------------------------------------- descriptor window (A.6)
@@ -1405,6 +1409,14 @@ __global__ __launch_bounds__(256) void k_quads(const uint8_t* __restrict__ img_b
 // exactness test (e.g. an orientation of exactly 90 degrees: cos = -4.4e-8) goes to list 4 and is described by
 // the sequential walk of k_describe.
 // ------------------------------------------------------------------------------------------------
+// sin/cos(float) are defined as the double functions rounded to float (see oracle_surf.cpp).  Out of line: the
+// double-precision argument reduction would otherwise set the register budget of the whole kernel.
+__device__ __noinline__ float2 direction_sincos(float dir) {
+    double sd, cd;
+    sincos((double)dir, &sd, &cd);
+    return make_float2((float)sd, (float)cd);
+}
+
 __device__ __forceinline__ bool exact_step(float v) { return v == 0.f || fabsf(v) >= 0x1p-17f; }
 __device__ __forceinline__ bool exact_start(float v) { return (v == 0.f || fabsf(v) >= 0x1p-17f) && fabsf(v) < 7000.f; }
 
@@ -1430,15 +1442,18 @@ __device__ __forceinline__ int bilinear_u8(uint32_t q, float a, float b) {
 // U samples of one lane at columns j0 + u * CB, all inside the window.  (px0, py0) is the exact position of
 // column j0, (dxs, dys) the exact step of CB columns.  Coordinates are linear in the column, so the batch lies
 // in the frame interior iff its first and last sample do; then the 2 * U tap loads go out back to back.
-template <int U, int CB>
+template <int U, int CB, bool CHECK>
 __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, const uint32_t* __restrict__ quad, int W,
                                              int ncols1, int nrows1, double px0, double py0, double dxs, double dys,
                                              lds_u8* wdst) {
-    const double pxl = px0 + (double)(U - 1) * dxs, pyl = py0 + (double)(U - 1) * dys;
-    const int ix0 = (int)floor(px0), iy0 = (int)floor(py0), ixl = (int)floor(pxl), iyl = (int)floor(pyl);
-    const bool ok = (unsigned)ix0 < (unsigned)ncols1 && (unsigned)iy0 < (unsigned)nrows1 &&
-                    (unsigned)ixl < (unsigned)ncols1 && (unsigned)iyl < (unsigned)nrows1;
-    if (__ballot(!ok) == 0ull) {
+    bool ok = true;
+    if (CHECK) {  // !CHECK: the caller has verified the whole strip of rows
+        const double pxl = px0 + (double)(U - 1) * dxs, pyl = py0 + (double)(U - 1) * dys;
+        const int ix0 = (int)floor(px0), iy0 = (int)floor(py0), ixl = (int)floor(pxl), iyl = (int)floor(pyl);
+        ok = (unsigned)ix0 < (unsigned)ncols1 && (unsigned)iy0 < (unsigned)nrows1 && (unsigned)ixl < (unsigned)ncols1 &&
+             (unsigned)iyl < (unsigned)nrows1;
+    }
+    if (!CHECK || __ballot(!ok) == 0ull) {
         float a[U], b[U];
         uint32_t q[U];
         double px = px0, py = py0;
@@ -1465,7 +1480,7 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
 }
 
 template <int WHI, int NW, int RB>
-__global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                             const uint32_t* __restrict__ quad_base,
                                                             const int32_t* __restrict__ sum_base, size_t sum_stride, int H,
                                                             int W, vo_keypoint* __restrict__ kp_base,
@@ -1520,8 +1535,9 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
         __syncthreads();
         const float descriptor_dir = s_dir;
         const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
-        const float sin_dir = -(float)sin((double)dir);
-        const float cos_dir = (float)cos((double)dir);
+        const float2 sc2 = direction_sincos(dir);
+        const float sin_dir = -sc2.x;
+        const float cos_dir = sc2.y;
         const float win_offset = -(float)(win - 1) / 2;
         const int ncols1 = W - 1, nrows1 = H - 1;
         const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
@@ -1539,7 +1555,7 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
                 v += inc;
             }
         }
-        if (!area_fast) describe_pix_tab(tid, NT, win, s_cell, s_pix);
+        if (!area_fast) describe_pix_tab(tid, NT, win, scale, s_cell, s_pix);
         __syncthreads();
 
         lds_u8* wbase = (lds_u8*)s_win + wave * (RB * kPitch);
@@ -1558,25 +1574,41 @@ __global__ __launch_bounds__(NW * 64) void k_describe_tiled(const uint8_t* __res
                 bad = bad || !(exact_start(start_x) && exact_start(start_y));
                 const double sxd = (double)start_x, syd = (double)start_y;
                 lds_u8* wrow = wbase + r * kPitch;
-                int jb = 0;
-#define VO_BATCH(UU)                                                                                                  \
-    {                                                                                                                 \
-        const double jd = (double)(jb + c);                                                                           \
-        sample_batch<UU, CB>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
-                             dys, wrow + jb + c);                                                                     \
-        jb += UU * CB;                                                                                                \
-    }
-                while (jb + 8 * CB <= win) VO_BATCH(8)
-                if (jb + 4 * CB <= win) VO_BATCH(4)
-                if (jb + 2 * CB <= win) VO_BATCH(2)
-                if (jb + CB <= win) VO_BATCH(1)
-#undef VO_BATCH
-                if (jb < win) {  // last, partial group of columns: lanes past the window repeat its last column
-                    const int jc = min(jb + c, win - 1);
-                    const double jd = (double)jc;
-                    sample_batch<1, CB>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs,
-                                        dys, wrow + jc);
+                // rows whose two ends lie in the frame interior are interior throughout (the walk is a straight line):
+                // one test per strip instead of one per batch
+                bool row_in;
+                {
+                    const double jl = (double)(win - 1);
+                    const double pxe = __builtin_fma(jl, dcos, sxd), pye = __builtin_fma(jl, ndsin, syd);
+                    row_in = (unsigned)(int)floor(sxd) < (unsigned)ncols1 && (unsigned)(int)floor(syd) < (unsigned)nrows1 &&
+                             (unsigned)(int)floor(pxe) < (unsigned)ncols1 && (unsigned)(int)floor(pye) < (unsigned)nrows1;
                 }
+                auto sample_rows = [&](auto chk) {
+                    constexpr bool CK = decltype(chk)::value;
+                    int jb = 0;
+#define VO_BATCH(UU)                                                                                                          \
+    {                                                                                                                         \
+        const double jd = (double)(jb + c);                                                                                   \
+        sample_batch<UU, CB, CK>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
+                                 dys, wrow + jb + c);                                                                         \
+        jb += UU * CB;                                                                                                        \
+    }
+                    while (jb + 8 * CB <= win) VO_BATCH(8)
+                    if (jb + 4 * CB <= win) VO_BATCH(4)
+                    if (jb + 2 * CB <= win) VO_BATCH(2)
+                    if (jb + CB <= win) VO_BATCH(1)
+#undef VO_BATCH
+                    if (jb < win) {  // last, partial group of columns: lanes past the window repeat its last column
+                        const int jc = min(jb + c, win - 1);
+                        const double jd = (double)jc;
+                        sample_batch<1, CB, CK>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd),
+                                                __builtin_fma(jd, ndsin, syd), dxs, dys, wrow + jc);
+                    }
+                };
+                if (__ballot(!row_in) == 0ull)
+                    sample_rows(std::false_type{});
+                else
+                    sample_rows(std::true_type{});
                 wave_sync_lds();
                 // INTER_AREA row pass: one (row, destination cell) per lane, the cell's pixels in table order
                 const int nrw = min(RB, win - wrow0);
