@@ -11,19 +11,23 @@ int main() {
     std::vector<uint8_t> a((size_t)H * W, 128), b((size_t)H * W, 128);
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) & 0xffff; };
-    for (int k = 0; k < 400; k++) {  // random spots at different depths: camera moves along x, disparity 10..40 px
-        const int cx = 40 + rnd() % (W - 100), cy = 40 + rnd() % (H - 80), amp = 40 + rnd() % 60;
-        const double sg = 1.5 + (rnd() % 300) / 100.0;
+    for (int k = 0; k < 400; k++) {  // textured features at different depths: camera moves along x, disparity 10..40 px
+        const int cx = 40 + rnd() % (W - 100), cy = 40 + rnd() % (H - 80);
         const int disp = 10 + rnd() % 31;
-        for (int y = -12; y <= 12; y++)
-            for (int x = -12; x <= 12; x++) {
-                const int v = (int)(amp * std::exp(-(x * x + y * y) / (2 * sg * sg)));
-                auto put = [&](std::vector<uint8_t>& im, int px, int py) {
-                    if (px >= 0 && px < W && py >= 0 && py < H) im[(size_t)py * W + px] = (uint8_t)std::min(255, im[(size_t)py * W + px] + v);
-                };
-                put(a, cx + x, cy + y);
-                put(b, cx + x - disp, cy + y);
-            }
+        for (int part = 0; part < 4; part++) {  // a spot and three random satellites give every feature an orientation
+            const int ox = part ? (int)(rnd() % 15) - 7 : 0, oy = part ? (int)(rnd() % 15) - 7 : 0;
+            const int amp = (part ? 20 : 40) + rnd() % 60;
+            const double sg = (part ? 1.0 : 1.5) + (rnd() % 250) / 100.0;
+            for (int y = -12; y <= 12; y++)
+                for (int x = -12; x <= 12; x++) {
+                    const int v = (int)(amp * std::exp(-(x * x + y * y) / (2 * sg * sg)));
+                    auto put = [&](std::vector<uint8_t>& im, int px, int py) {
+                        if (px >= 0 && px < W && py >= 0 && py < H) im[(size_t)py * W + px] = (uint8_t)std::min(255, im[(size_t)py * W + px] + v);
+                    };
+                    put(a, cx + ox + x, cy + oy + y);
+                    put(b, cx + ox + x - disp, cy + oy + y);
+                }
+        }
     }
     try {
         vo::Frontend fe;

@@ -1380,6 +1380,23 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     }  // work queue
 }
 
+// a5 as its own launch: one wavefront per keypoint, four keypoints per workgroup.  Keeping it out of the descriptor
+// kernel takes its registers and LDS off that kernel's budget and leaves no wavefront idle while one computes the angle.
+__global__ __launch_bounds__(256) void k_orientation(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+                                                     vo_keypoint* __restrict__ kp_base, int cap,
+                                                     const FrameCounters* __restrict__ cnt) {
+    __shared__ float s_X[4][kOriSamples + 15], s_Y[4][kOriSamples + 15];
+    __shared__ int s_A[4][kOriSamples + 15];
+    __shared__ float s_dir[4];
+    const int frame = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.x * 4 + wave;
+    if (k >= min(cnt[frame].n_raw, cap)) return;
+    vo_keypoint* kpp = kp_base + (size_t)frame * cap + k;
+    const float s = kpp->size * 1.2f / 9.0f;
+    describe_orientation(sum_base + (size_t)frame * sum_stride, W + 1, H, W, kpp->x, kpp->y, s, lane, lane, s_X[wave], s_Y[wave],
+                         s_A[wave], kpp, &s_dir[wave]);
+}
+
 // Bilinear footprint image for the descriptor sampler: one aligned 32-bit word per pixel holds the 2x2 taps
 // (p00 | p01 << 8 | p10 << 16 | p11 << 24), so a sample costs ONE gather instead of two unaligned 16-bit ones
 // (tools/microbench/gather_bench.hip: 2.2-2.5x the gather rate of the u8 image on gfx950).  The last row and
@@ -1462,7 +1479,10 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
             // interior samples have px, py >= 0: truncation is floor, and fract(p) = p - floor(p) exactly
             a[u] = (float)__builtin_amdgcn_fract(px);
             b[u] = (float)__builtin_amdgcn_fract(py);
-            q[u] = quad[(uint32_t)__mul24((int)py, W) + (uint32_t)(int)px];
+            asm volatile("" : "+v"(a[u]), "+v"(b[u]));  // keep the fractions as floats (not as doubles) across the loads
+            // 32-bit byte offset from the frame's base (a frame's footprint image is < 4 GB): scalar base + vector offset
+            const uint32_t boff = ((uint32_t)__mul24((int)py, W) + (uint32_t)(int)px) << 2;
+            q[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(quad) + boff);
             px += dxs;
             py += dys;
         }
@@ -1479,8 +1499,10 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
     }
 }
 
-template <int WHI, int NW, int RB>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
+// WHI: largest window of the class; NW wavefronts per keypoint; a gather covers RB rows x 64/RB columns; UMAX gathers in
+// flight per lane; a strip is G groups of RB rows per wavefront (sampled back to back, then one row pass and one fold).
+template <int WHI, int NW, int RB, int UMAX, int G>
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                             const uint32_t* __restrict__ quad_base,
                                                             const int32_t* __restrict__ sum_base, size_t sum_stride, int H,
                                                             int W, vo_keypoint* __restrict__ kp_base,
@@ -1489,51 +1511,67 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                                                             int* __restrict__ seq_list, int force_seq) {
     constexpr int NT = NW * 64;
     constexpr int CB = 64 / RB;                    // columns of one gather
-    constexpr int RS = NW * RB;                    // rows of one strip
+    constexpr int WR = RB * G;                     // rows of one wavefront in a strip
+    constexpr int RS = NW * WR;                    // rows of one strip
+    constexpr int NBUF = NW > 1 ? 2 : 1;           // row-pass results are double-buffered only across wavefronts
     constexpr int kPitch = ((WHI + 3) & ~3) + 4;   // bytes per strip row: an odd number of dwords
     static_assert(((kPitch / 4) & 1) == 1, "strip pitch must be an odd number of dwords");
-    __shared__ float s_X[kOriSamples + 15], s_Y[kOriSamples + 15];
-    __shared__ int s_A[kOriSamples + 15];
     __shared__ CellTab s_cell[kPatch + 1];
-    __shared__ PixTab s_pix[WHI];
-    __shared__ __attribute__((aligned(16))) uint8_t s_win[NW * RB * kPitch];
-    __shared__ float s_rowv[2 * RS * (kPatch + 1)];  // row-pass results of a strip (float, or int for integer scales)
-    __shared__ float s_sx[WHI], s_sy[WHI];           // start of every window row (sequential float accumulation)
-    __shared__ float s_grad[2 * kPatch * kPatch];
+    // strip-phase arrays; the gradient planes of the last phase (s_grad, 3200 B) reuse the same bytes
+    constexpr int kOffPix = 0, kOffSx = kOffPix + WHI * (int)sizeof(PixTab), kOffSy = kOffSx + WHI * 4;
+    constexpr int kOffWin = (kOffSy + WHI * 4 + 15) & ~15, kOffRowv = (kOffWin + RS * kPitch + 15) & ~15;
+    constexpr int kStripBytes = kOffRowv + NBUF * RS * (kPatch + 1) * 4, kGradBytes = 2 * kPatch * kPatch * 4;
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStripBytes > kGradBytes ? kStripBytes : kGradBytes];
+    PixTab* s_pix = reinterpret_cast<PixTab*>(s_raw + kOffPix);
+    float* s_sx = reinterpret_cast<float*>(s_raw + kOffSx);   // start of every window row (sequential float accumulation)
+    float* s_sy = reinterpret_cast<float*>(s_raw + kOffSy);
+    uint8_t* s_win = s_raw + kOffWin;
+    float* s_rowv = reinterpret_cast<float*>(s_raw + kOffRowv);  // row-pass results of a strip (float, or int for integer scales)
+    float* s_grad = reinterpret_cast<float*>(s_raw);
     __shared__ uint8_t s_patch[(kPatch + 1) * (kPatch + 1) + 7];
     __shared__ float s_vec[64];
-    __shared__ float s_dir;
-    __shared__ int s_item;
+    __shared__ int s_q[8];  // the keypoint being described: ticket, frame * cap + k, then x, y, size, angle as bits
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int r = lane / CB, c = lane - r * CB;
-    const int sw = W + 1;
     const int n_items = cls_cnt[cls];
+    // Work queue with a one-keypoint look-ahead: thread 0 draws the NEXT ticket, list entry and keypoint record
+    // while the workgroup describes the current one, so the three dependent global round trips (atomic, list,
+    // record) are off the critical path of a keypoint.
+    if (tid == 0) {
+        const int it = atomicAdd(&cls_cnt[8 + cls], 1);
+        s_q[0] = it;
+        if (it < n_items) {
+            const int cd = list[it];
+            const vo_keypoint* kq = kp_base + cd;
+            s_q[1] = cd;
+            s_q[2] = __float_as_int(kq->x);
+            s_q[3] = __float_as_int(kq->y);
+            s_q[4] = __float_as_int(kq->size);
+            s_q[5] = __float_as_int(kq->angle);
+        }
+    }
     for (;;) {
-        __syncthreads();  // previous keypoint's LDS is no longer read
-        if (tid == 0) s_item = atomicAdd(&cls_cnt[8 + cls], 1);
-        __syncthreads();
-        const int item = s_item;
+        __syncthreads();  // s_q is written; the previous keypoint's LDS is no longer read
+        const int item = s_q[0];
         if (item >= n_items) break;
-        const int code = list[item];
+        const int code = s_q[1];
+        const float cx = __int_as_float(s_q[2]), cy = __int_as_float(s_q[3]), size = __int_as_float(s_q[4]);
+        const float descriptor_dir = __int_as_float(s_q[5]);  // k_orientation
         const int frame = code / cap, k = code - frame * cap;
-        vo_keypoint* kpp = kp_base + (size_t)frame * cap + k;
-        const float size = kpp->size;
-        const float cx = kpp->x, cy = kpp->y;
+        int n_item = 0, n_code = 0;
+        if (tid == 0) n_item = atomicAdd(&cls_cnt[8 + cls], 1);  // look-ahead stage 1: ticket
         const float s = size * 1.2f / 9.0f;
         const int win = (int)((kPatch + 1) * s);
         const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
         const uint32_t* __restrict__ quad = quad_base + (size_t)frame * img_stride;
-        const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
-
-        if (tid < 64) describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_X, s_Y, s_A, kpp, &s_dir);
         const double scale = (double)win / (kPatch + 1);
         const int iscale = d_cvRoundD(scale);
         const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
         if (!area_fast && tid <= kPatch) describe_cell_tab(tid, win, scale, s_cell);
         __syncthreads();
-        const float descriptor_dir = s_dir;
+        if (tid == 0) n_code = *(volatile const int*)&list[min(n_item, n_items - 1)];  // look-ahead stage 2: list entry
         const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
         const float2 sc2 = direction_sincos(dir);
         const float sin_dir = -sc2.x;
@@ -1558,24 +1596,26 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
         if (!area_fast) describe_pix_tab(tid, NT, win, scale, s_cell, s_pix);
         __syncthreads();
 
-        lds_u8* wbase = (lds_u8*)s_win + wave * (RB * kPitch);
+        lds_u8* wbase = (lds_u8*)s_win + wave * (WR * kPitch);
         int* s_rowi = reinterpret_cast<int*>(s_rowv);
         // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane)
         float vacc = 0.f;
         int viacc = 0, dy = 0, left = iscale;
 
-        for (int i0 = 0, sidx = 0; i0 < win; i0 += RS, sidx ^= 1) {
-            const int wrow0 = i0 + wave * RB;  // first row of this wavefront's part of the strip
+        for (int i0 = 0, sidx = 0; i0 < win; i0 += RS, sidx ^= (NBUF - 1)) {
+            const int wrow0 = i0 + wave * WR;  // first row of this wavefront's part of the strip
             if (wrow0 < win) {
-                // idle rows of the window's last strip repeat the wavefront's first row (always inside the window), so
+              for (int g = 0; g < G && wrow0 + g * RB < win; g++) {
+                const int grow0 = wrow0 + g * RB;
+                // idle rows of the window's last group repeat the group's first row (always inside the window), so
                 // that every lane computes a valid sample and no load needs a guard
-                const int irow = wrow0 + r < win ? wrow0 + r : wrow0;
+                const int irow = grow0 + r < win ? grow0 + r : grow0;
                 const float start_x = s_sx[irow], start_y = s_sy[irow];
                 bad = bad || !(exact_start(start_x) && exact_start(start_y));
                 const double sxd = (double)start_x, syd = (double)start_y;
-                lds_u8* wrow = wbase + r * kPitch;
+                lds_u8* wrow = wbase + (g * RB + r) * kPitch;
                 // rows whose two ends lie in the frame interior are interior throughout (the walk is a straight line):
-                // one test per strip instead of one per batch
+                // one test per group instead of one per batch
                 bool row_in;
                 {
                     const double jl = (double)(win - 1);
@@ -1593,8 +1633,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                                  dys, wrow + jb + c);                                                                         \
         jb += UU * CB;                                                                                                        \
     }
-                    while (jb + 8 * CB <= win) VO_BATCH(8)
-                    if (jb + 4 * CB <= win) VO_BATCH(4)
+                    if constexpr (UMAX >= 8) {
+                        while (jb + 8 * CB <= win) VO_BATCH(8)
+                        if (jb + 4 * CB <= win) VO_BATCH(4)
+                    } else {
+                        while (jb + 4 * CB <= win) VO_BATCH(4)
+                    }
                     if (jb + 2 * CB <= win) VO_BATCH(2)
                     if (jb + CB <= win) VO_BATCH(1)
 #undef VO_BATCH
@@ -1609,14 +1653,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                     sample_rows(std::false_type{});
                 else
                     sample_rows(std::true_type{});
+              }
                 wave_sync_lds();
                 // INTER_AREA row pass: one (row, destination cell) per lane, the cell's pixels in table order
-                const int nrw = min(RB, win - wrow0);
+                const int nrw = min(WR, win - wrow0);
                 const int nub = (int)scale + 1;
                 for (int it = lane; it < nrw * (kPatch + 1); it += 64) {
                     const int rr = it / (kPatch + 1), cell = it - rr * (kPatch + 1);
                     const lds_u8* p = wbase + rr * kPitch;
-                    const int o = (sidx * RS + wave * RB + rr) * (kPatch + 1) + cell;
+                    const int o = (sidx * RS + wave * WR + rr) * (kPatch + 1) + cell;
                     if (area_fast) {
                         int tot = 0;
                         for (int q = cell * iscale; q < (cell + 1) * iscale; q++) tot += p[q];
@@ -1670,18 +1715,40 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(4, 8)))
                         }
                     }
                 } else {
-                    for (int q = 0; q < nrows; q++) {
-                        const PixTab t = s_pix[i0 + q];
-                        const float val = s_rowv[ob + q * (kPatch + 1)];
-                        vacc += t.w_cur * val;
-                        if (__builtin_amdgcn_readfirstlane(t.end)) {  // same row in every lane
-                            s_patch[dy * (kPatch + 1) + tid] = (uint8_t)saturate_u8(d_cvRoundF(vacc));
-                            dy++;
-                            vacc = t.w_next * val;
+                    // eight rows at a time: their table entries and row sums are read together, the adds stay in row order
+                    for (int q0 = 0; q0 < nrows; q0 += 8) {
+                        PixTab t[8];
+                        float val[8];
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            const int q = min(q0 + u, nrows - 1);
+                            t[u] = s_pix[i0 + q];
+                            val[u] = s_rowv[ob + q * (kPatch + 1)];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 8; u++) {
+                            if (q0 + u < nrows) {
+                                vacc += t[u].w_cur * val[u];
+                                if (__builtin_amdgcn_readfirstlane(t[u].end)) {  // same row in every lane
+                                    s_patch[dy * (kPatch + 1) + tid] = (uint8_t)saturate_u8(d_cvRoundF(vacc));
+                                    dy++;
+                                    vacc = t[u].w_next * val[u];
+                                }
+                            }
                         }
                     }
                 }
             }
+        }
+        if (tid == 0) {  // look-ahead stage 3: the next keypoint's record (every thread has read s_q: barriers passed)
+            const volatile float* kq = reinterpret_cast<const volatile float*>(kp_base + n_code);
+            const float nx = kq[0], ny = kq[1], nsz = kq[2], nan_ = kq[3];
+            s_q[0] = n_item;
+            s_q[1] = n_code;
+            s_q[2] = __float_as_int(nx);
+            s_q[3] = __float_as_int(ny);
+            s_q[4] = __float_as_int(nsz);
+            s_q[5] = __float_as_int(nan_);
         }
         if (__syncthreads_or(bad ? 1 : 0)) {
             // coordinates are not exactly representable in closed form: sequential walk (k_describe, list 4)
@@ -1773,17 +1840,19 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             const size_t ls = (size_t)fs.F * fs.cap;
             hipLaunchKernelGGL(k_classify, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt,
                                fs.cls_list, ls, fs.cls_cnt);
+            hipLaunchKernelGGL(k_orientation, dim3((fs.cap + 3) / 4, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(), fs.H,
+                               fs.W, fs.kp, fs.cap, fs.cnt);
             hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                                fs.H, fs.W, fs.quad);
-#define LAUNCH_TILED(HI, NW, RB, CLS, GRID)                                                                           \
-    hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img, fs.img_stride(), \
+#define LAUNCH_TILED(HI, NW, RB, UMAX, G, CLS, GRID)                                                                           \
+    hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB, UMAX, G>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img, fs.img_stride(), \
                        fs.quad, fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, \
                        CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe)
             // heaviest class first so that its long keypoints overlap the many short ones that follow
-            LAUNCH_TILED(kBigWin, 4, 8, 3, 768);
-            LAUNCH_TILED(kMidWin, 4, 8, 2, 1024);
-            LAUNCH_TILED(kSmallWin, 1, 8, 1, 4096);
-            LAUNCH_TILED(64, 1, 8, 0, 4096);
+            LAUNCH_TILED(kBigWin, 4, 8, 8, 1, 3, 768);
+            LAUNCH_TILED(kMidWin, 4, 8, 8, 1, 2, 1280);
+            LAUNCH_TILED(kSmallWin, 1, 8, 8, 4, 1, 5120);
+            LAUNCH_TILED(64, 1, 8, 4, 4, 0, 5120);
 #undef LAUNCH_TILED
             // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
             hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.sum,
