@@ -378,7 +378,131 @@ __device__ bool kp_describable(float cx, float cy, float size, int H, int W) {
     return false;
 }
 
-constexpr int kGlobalTileLds = kLayersPerOctave * kHY * kHP * 4;
+// a3: non-maximum suppression + interpolation of one tile whose five det planes are in LDS (plane p, row y, column x at
+// s_det[p * PLANE + y * DP + x]; the interior sample (yy, xx) sits at row yy + 1, column xx + 1).
+// Two passes: every interior sample of layers 1..3 is tested against the threshold and its 8 neighbours of the same
+// layer, survivors (a few per cent) are compacted into an LDS queue; the queue is then walked with full wavefronts for
+// the 18 neighbours of the adjacent layers, the interpolation and the append.  Keypoints are appended in
+// arbitrary order (a4 sorts them by a total order).
+constexpr int kNmsQueue = 1023;  // entries; a 2-D strict local maximum is at most every 4th sample of 3 * 32 * 32
+
+template <int TI, int DP, int PLANE>
+__device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o, int ty, int tx, int H, int W, float thr,
+                                         const int32_t* __restrict__ sum, vo_keypoint* __restrict__ kps, int cap,
+                                         FrameCounters* __restrict__ cnt_frame, int filter_invalid) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int step = 1 << o, sw = W + 1;
+    const int lrows = H / step, lcols = W / step;
+    if (tid == 0) s_queue[0] = 0;
+    __syncthreads();
+    for (int l = 1; l <= 3; l++) {
+        const int size_next = c_tab.layers[o * kLayersPerOctave + l + 1].size;
+        const int margin = (size_next / 2) / step + 1;
+        for (int s0 = 0; s0 < TI * TI; s0 += 256) {
+            const int s = s0 + tid;
+            const int yy = s / TI, xx = s - yy * TI;
+            const int i = ty * TI + yy, j = tx * TI + xx;
+            bool cand = false;
+            if (s < TI * TI && i >= margin && i < lrows - margin && j >= margin && j < lcols - margin) {
+                const float* p = s_det + l * PLANE + (yy + 1) * DP + (xx + 1);
+                const float v = p[0];
+                if (v > thr)
+                    cand = v > p[-DP - 1] && v > p[-DP] && v > p[-DP + 1] && v > p[-1] && v > p[1] && v > p[DP - 1] && v > p[DP] &&
+                           v > p[DP + 1];
+            }
+            const unsigned long long m = __ballot(cand);
+            if (m) {
+                int base = 0;
+                if (lane == 0) base = atomicAdd(&s_queue[0], __popcll(m));
+                base = __shfl(base, 0, 64);
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (cand && pos < kNmsQueue) s_queue[1 + pos] = (l << 20) | (yy << 10) | xx;
+            }
+        }
+    }
+    __syncthreads();
+    const int nq = min(s_queue[0], kNmsQueue);
+    for (int q0 = 0; q0 < nq; q0 += 256) {
+        const int q = q0 + tid;
+        bool emit = false;
+        vo_keypoint kpt;
+        if (q < nq) {
+            const int code = s_queue[1 + q];
+            const int l = code >> 20, yy = (code >> 10) & 1023, xx = code & 1023;
+            const int i = ty * TI + yy, j = tx * TI + xx;
+            const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
+            const int size = L.size;
+            const int size_prev = c_tab.layers[o * kLayersPerOctave + l - 1].size;
+            float N9[3][9];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int t = 0; t < 9; t++) N9[a][t] = s_det[(l - 1 + a) * PLANE + (yy + t / 3) * DP + (xx + t % 3)];
+            const float val0 = N9[1][4];
+            bool is_max = true;
+#pragma unroll
+            for (int a = 0; a < 3; a += 2)
+#pragma unroll
+                for (int t = 0; t < 9; t++) is_max = is_max && (val0 > N9[a][t]);
+            if (is_max) {
+                const int sum_i = step * (i - (size / 2) / step);
+                const int sum_j = step * (j - (size / 2) / step);
+                const float center_i = sum_i + (size - 1) * 0.5f;
+                const float center_j = sum_j + (size - 1) * 0.5f;
+                // interpolateKeypoint, Cramer's rule in float
+                const float b0 = -(N9[1][5] - N9[1][3]) / 2;
+                const float b1 = -(N9[1][7] - N9[1][1]) / 2;
+                const float b2 = -(N9[2][4] - N9[0][4]) / 2;
+                const float a00 = N9[1][3] - 2 * N9[1][4] + N9[1][5];
+                const float a01 = (N9[1][8] - N9[1][6] - N9[1][2] + N9[1][0]) / 4;
+                const float a02 = (N9[2][5] - N9[2][3] - N9[0][5] + N9[0][3]) / 4;
+                const float a10 = a01;
+                const float a11 = N9[1][1] - 2 * N9[1][4] + N9[1][7];
+                const float a12 = (N9[2][7] - N9[2][1] - N9[0][7] + N9[0][1]) / 4;
+                const float a20 = a02, a21 = a12;
+                const float a22 = N9[0][4] - 2 * N9[1][4] + N9[2][4];
+                float d = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) + a02 * (a10 * a21 - a20 * a11);
+                float x0 = 0, x1 = 0, x2 = 0;
+                if (d != 0) {
+                    d = 1 / d;
+                    x0 = d * (b0 * (a11 * a22 - a12 * a21) - a01 * (b1 * a22 - a12 * b2) + a02 * (b1 * a21 - a11 * b2));
+                    x1 = d * (a00 * (b1 * a22 - a12 * b2) - b0 * (a10 * a22 - a12 * a20) + a02 * (a10 * b2 - b1 * a20));
+                    x2 = d * (a00 * (a11 * b2 - b1 * a21) - a01 * (a10 * b2 - b1 * a20) + b0 * (a10 * a21 - a11 * a20));
+                }
+                const bool ok = (x0 != 0 || x1 != 0 || x2 != 0) && fabsf(x0) <= 1 && fabsf(x1) <= 1 && fabsf(x2) <= 1;
+                if (ok) {
+                    const int ds = size - size_prev;
+                    kpt.x = center_j + x0 * step;
+                    kpt.y = center_i + x1 * step;
+                    kpt.size = (float)d_cvRoundF((float)size + x2 * ds);
+                    kpt.angle = -1.f;
+                    kpt.response = val0;
+                    kpt.octave = o;
+                    // trace at the same sample (the product path never materialises it)
+                    float dx, dy, dxy;
+                    hessian_boxes(L, sum + (size_t)((i - L.margin) * step) * sw + (j - L.margin) * step, sw, dx, dy, dxy);
+                    const float tr = dx + dy;
+                    kpt.class_id = (tr > 0) - (tr < 0);
+                    emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W);
+                }
+            }
+        }
+        // wavefront-ballot compaction: one atomic per wave
+        const unsigned long long m = __ballot(emit);
+        if (m) {
+            int base = 0;
+            if (lane == 0) base = atomicAdd(&cnt_frame->n_raw, __popcll(m));
+            base = __shfl(base, 0, 64);
+            if (emit) {
+                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                if (pos < cap) kps[pos] = kpt;
+            }
+        }
+    }
+}
+
+constexpr int kGlobalTileDet = kLayersPerOctave * kHY * kHP * 4;
+constexpr int kGlobalTileLds = kGlobalTileDet + (kNmsQueue + 1) * 4;
 
 __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int b, int frame,
                                                         const int32_t* __restrict__ sum_base, size_t sum_stride,
@@ -393,7 +517,7 @@ __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int
     const int ty = b / g.tiles_x[o], tx = b - ty * g.tiles_x[o];
     const int H = g.H, W = g.W, sw = W + 1;
     const int step = 1 << o;
-    const int lrows = H / step, lcols = W / step;
+    (void)0;
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
     const int tid = threadIdx.x;
     const int i0 = ty * kTY - 1, j0 = tx * kTX - 1;
@@ -417,96 +541,8 @@ __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int
     }
     __syncthreads();
 
-    vo_keypoint* __restrict__ kps = kp_base + (size_t)frame * cap;
-    const int lane = tid & 63;
-    for (int l = 1; l <= 3; l++) {
-        const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
-        const int size = L.size;
-        const int size_next = c_tab.layers[o * kLayersPerOctave + l + 1].size;
-        const int size_prev = c_tab.layers[o * kLayersPerOctave + l - 1].size;
-        const int margin = (size_next / 2) / step + 1;
-        for (int s = tid; s < kTY * kTX; s += 256) {
-            const int yy = s >> 5, xx = s & 31;
-            const int i = ty * kTY + yy, j = tx * kTX + xx;
-            bool emit = false;
-            vo_keypoint kpt;
-            if (i >= margin && i < lrows - margin && j >= margin && j < lcols - margin) {
-                const float val0 = s_det[l][yy + 1][xx + 1];
-                if (val0 > thr) {
-                    float N9[3][9];
-#pragma unroll
-                    for (int a = 0; a < 3; a++)
-#pragma unroll
-                        for (int q = 0; q < 9; q++) N9[a][q] = s_det[l - 1 + a][yy + q / 3][xx + q % 3];
-                    bool is_max = true;
-#pragma unroll
-                    for (int a = 0; a < 3; a++)
-#pragma unroll
-                        for (int q = 0; q < 9; q++)
-                            if (!(a == 1 && q == 4)) is_max = is_max && (val0 > N9[a][q]);
-                    if (is_max) {
-                        const int sum_i = step * (i - (size / 2) / step);
-                        const int sum_j = step * (j - (size / 2) / step);
-                        const float center_i = sum_i + (size - 1) * 0.5f;
-                        const float center_j = sum_j + (size - 1) * 0.5f;
-                        // interpolateKeypoint, Cramer's rule in float
-                        const float b0 = -(N9[1][5] - N9[1][3]) / 2;
-                        const float b1 = -(N9[1][7] - N9[1][1]) / 2;
-                        const float b2 = -(N9[2][4] - N9[0][4]) / 2;
-                        const float a00 = N9[1][3] - 2 * N9[1][4] + N9[1][5];
-                        const float a01 = (N9[1][8] - N9[1][6] - N9[1][2] + N9[1][0]) / 4;
-                        const float a02 = (N9[2][5] - N9[2][3] - N9[0][5] + N9[0][3]) / 4;
-                        const float a10 = a01;
-                        const float a11 = N9[1][1] - 2 * N9[1][4] + N9[1][7];
-                        const float a12 = (N9[2][7] - N9[2][1] - N9[0][7] + N9[0][1]) / 4;
-                        const float a20 = a02, a21 = a12;
-                        const float a22 = N9[0][4] - 2 * N9[1][4] + N9[2][4];
-                        float d = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) +
-                                  a02 * (a10 * a21 - a20 * a11);
-                        float x0 = 0, x1 = 0, x2 = 0;
-                        if (d != 0) {
-                            d = 1 / d;
-                            x0 = d * (b0 * (a11 * a22 - a12 * a21) - a01 * (b1 * a22 - a12 * b2) +
-                                      a02 * (b1 * a21 - a11 * b2));
-                            x1 = d * (a00 * (b1 * a22 - a12 * b2) - b0 * (a10 * a22 - a12 * a20) +
-                                      a02 * (a10 * b2 - b1 * a20));
-                            x2 = d * (a00 * (a11 * b2 - b1 * a21) - a01 * (a10 * b2 - b1 * a20) +
-                                      b0 * (a10 * a21 - a11 * a20));
-                        }
-                        const bool ok = (x0 != 0 || x1 != 0 || x2 != 0) && fabsf(x0) <= 1 && fabsf(x1) <= 1 &&
-                                        fabsf(x2) <= 1;
-                        if (ok) {
-                            const int ds = size - size_prev;
-                            kpt.x = center_j + x0 * step;
-                            kpt.y = center_i + x1 * step;
-                            kpt.size = (float)d_cvRoundF((float)size + x2 * ds);
-                            kpt.angle = -1.f;
-                            kpt.response = val0;
-                            kpt.octave = o;
-                            // trace at the same sample (the product path never materialises it)
-                            float dx, dy, dxy;
-                            hessian_boxes(L, sum + (size_t)((i - L.margin) * step) * sw + (j - L.margin) * step, sw,
-                                          dx, dy, dxy);
-                            const float tr = dx + dy;
-                            kpt.class_id = (tr > 0) - (tr < 0);
-                            emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W);
-                        }
-                    }
-                }
-            }
-            // wavefront-ballot compaction: one atomic per wave
-            const unsigned long long m = __ballot(emit);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&cnt[frame].n_raw, __popcll(m));
-                base = __shfl(base, 0, 64);
-                if (emit) {
-                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < cap) kps[pos] = kpt;
-                }
-            }
-        }
-    }
+    nms_tile<kTX, kHP, kHY * kHP>(&s_det[0][0][0], reinterpret_cast<int*>(smem + kGlobalTileDet), o, ty, tx, H, W, thr, sum,
+                                  kp_base + (size_t)frame * cap, cap, cnt + frame, filter_invalid);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -550,7 +586,7 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     const int o = O;
     const int ty = b / tiles_x, tx = b - ty * tiles_x;
     const int sw = W + 1;
-    const int lrows = H / step, lcols = W / step;
+    (void)0;
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
     const int tid = threadIdx.x;
     const int i0 = ty * TI - 1, j0 = tx * TI - 1;
@@ -611,96 +647,9 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     }
     __syncthreads();
 
-    vo_keypoint* __restrict__ kps = kp_base + (size_t)frame * cap;
-    const int lane = tid & 63;
-    for (int l = 1; l <= 3; l++) {
-        const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
-        const int size = L.size;
-        const int size_next = c_tab.layers[o * kLayersPerOctave + l + 1].size;
-        const int size_prev = c_tab.layers[o * kLayersPerOctave + l - 1].size;
-        const int margin = (size_next / 2) / step + 1;
-        for (int s = tid; s < TI * TI; s += 256) {
-            const int yy = s / TI, xx = s - yy * TI;
-            const int i = ty * TI + yy, j = tx * TI + xx;
-            bool emit = false;
-            vo_keypoint kpt;
-            if (i >= margin && i < lrows - margin && j >= margin && j < lcols - margin) {
-                const float val0 = s_det[l][yy + 1][xx + 1];
-                if (val0 > thr) {
-                    float N9[3][9];
-#pragma unroll
-                    for (int a = 0; a < 3; a++)
-#pragma unroll
-                        for (int q = 0; q < 9; q++) N9[a][q] = s_det[l - 1 + a][yy + q / 3][xx + q % 3];
-                    bool is_max = true;
-#pragma unroll
-                    for (int a = 0; a < 3; a++)
-#pragma unroll
-                        for (int q = 0; q < 9; q++)
-                            if (!(a == 1 && q == 4)) is_max = is_max && (val0 > N9[a][q]);
-                    if (is_max) {
-                        const int sum_i = step * (i - (size / 2) / step);
-                        const int sum_j = step * (j - (size / 2) / step);
-                        const float center_i = sum_i + (size - 1) * 0.5f;
-                        const float center_j = sum_j + (size - 1) * 0.5f;
-                        // interpolateKeypoint, Cramer's rule in float
-                        const float b0 = -(N9[1][5] - N9[1][3]) / 2;
-                        const float b1 = -(N9[1][7] - N9[1][1]) / 2;
-                        const float b2 = -(N9[2][4] - N9[0][4]) / 2;
-                        const float a00 = N9[1][3] - 2 * N9[1][4] + N9[1][5];
-                        const float a01 = (N9[1][8] - N9[1][6] - N9[1][2] + N9[1][0]) / 4;
-                        const float a02 = (N9[2][5] - N9[2][3] - N9[0][5] + N9[0][3]) / 4;
-                        const float a10 = a01;
-                        const float a11 = N9[1][1] - 2 * N9[1][4] + N9[1][7];
-                        const float a12 = (N9[2][7] - N9[2][1] - N9[0][7] + N9[0][1]) / 4;
-                        const float a20 = a02, a21 = a12;
-                        const float a22 = N9[0][4] - 2 * N9[1][4] + N9[2][4];
-                        float d = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) +
-                                  a02 * (a10 * a21 - a20 * a11);
-                        float x0 = 0, x1 = 0, x2 = 0;
-                        if (d != 0) {
-                            d = 1 / d;
-                            x0 = d * (b0 * (a11 * a22 - a12 * a21) - a01 * (b1 * a22 - a12 * b2) +
-                                      a02 * (b1 * a21 - a11 * b2));
-                            x1 = d * (a00 * (b1 * a22 - a12 * b2) - b0 * (a10 * a22 - a12 * a20) +
-                                      a02 * (a10 * b2 - b1 * a20));
-                            x2 = d * (a00 * (a11 * b2 - b1 * a21) - a01 * (a10 * b2 - b1 * a20) +
-                                      b0 * (a10 * a21 - a11 * a20));
-                        }
-                        const bool ok = (x0 != 0 || x1 != 0 || x2 != 0) && fabsf(x0) <= 1 && fabsf(x1) <= 1 &&
-                                        fabsf(x2) <= 1;
-                        if (ok) {
-                            const int ds = size - size_prev;
-                            kpt.x = center_j + x0 * step;
-                            kpt.y = center_i + x1 * step;
-                            kpt.size = (float)d_cvRoundF((float)size + x2 * ds);
-                            kpt.angle = -1.f;
-                            kpt.response = val0;
-                            kpt.octave = o;
-                            // trace at the same sample (the product path never materialises it)
-                            float dx, dy, dxy;
-                            hessian_boxes(L, sum + (size_t)((i - L.margin) * step) * sw + (j - L.margin) * step, sw,
-                                          dx, dy, dxy);
-                            const float tr = dx + dy;
-                            kpt.class_id = (tr > 0) - (tr < 0);
-                            emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W);
-                        }
-                    }
-                }
-            }
-            // wavefront-ballot compaction: one atomic per wave
-            const unsigned long long m = __ballot(emit);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&cnt[frame].n_raw, __popcll(m));
-                base = __shfl(base, 0, 64);
-                if (emit) {
-                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                    if (pos < cap) kps[pos] = kpt;
-                }
-            }
-        }
-    }
+    // the integral patch is dead from here on: its first words hold the candidate queue
+    nms_tile<TI, DP, T * DP>(&s_det[0][0][0], reinterpret_cast<int*>(s_sum), o, ty, tx, H, W, thr, sum, kp_base + (size_t)frame * cap,
+                             cap, cnt + frame, filter_invalid);
 }
 
 // octave-0 tiles (LDS patch) and the few tiles of octaves >= OG (taps from L1/L2) in ONE grid, so that the long,
