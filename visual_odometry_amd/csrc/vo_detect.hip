@@ -390,7 +390,7 @@ template <int TI, int DP, int PLANE>
 __device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o, int ty, int tx, int H, int W, float thr,
                                          const int32_t* __restrict__ sum, vo_keypoint* __restrict__ kps, int cap,
                                          FrameCounters* __restrict__ cnt_frame, int filter_invalid) {
-    const int tid = threadIdx.x, lane = tid & 63;
+    const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
     const int step = 1 << o, sw = W + 1;
     const int lrows = H / step, lcols = W / step;
     if (tid == 0) s_queue[0] = 0;
@@ -398,7 +398,7 @@ __device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o
     for (int l = 1; l <= 3; l++) {
         const int size_next = c_tab.layers[o * kLayersPerOctave + l + 1].size;
         const int margin = (size_next / 2) / step + 1;
-        for (int s0 = 0; s0 < TI * TI; s0 += 256) {
+        for (int s0 = 0; s0 < TI * TI; s0 += NT) {
             const int s = s0 + tid;
             const int yy = s / TI, xx = s - yy * TI;
             const int i = ty * TI + yy, j = tx * TI + xx;
@@ -422,7 +422,7 @@ __device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o
     }
     __syncthreads();
     const int nq = min(s_queue[0], kNmsQueue);
-    for (int q0 = 0; q0 < nq; q0 += 256) {
+    for (int q0 = 0; q0 < nq; q0 += NT) {
         const int q = q0 + tid;
         bool emit = false;
         vo_keypoint kpt;
@@ -527,7 +527,7 @@ __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int
         const bool fits = (L.size <= H && L.size <= W);
         const int samples_i = fits ? 1 + (H - L.size) / step : 0;
         const int samples_j = fits ? 1 + (W - L.size) / step : 0;
-        for (int s = tid; s < kHY * kHX; s += 256) {
+        for (int s = tid; s < kHY * kHX; s += (int)blockDim.x) {
             const int yy = s / kHX, xx = s - yy * kHX;
             const int oi = i0 + yy - L.margin, oj = j0 + xx - L.margin;
             float dv = 0.f;
@@ -588,19 +588,19 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     const int sw = W + 1;
     (void)0;
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, NT = blockDim.x;
     const int i0 = ty * TI - 1, j0 = tx * TI - 1;
     const int prow0 = (i0 - kMarginMax) * step, pcol0 = (j0 - kMarginMax) * step;
 
     {
         // patch rows go round the four wavefronts, 64 consecutive columns per load; RU rows (RU * KC loads) in flight
         constexpr int RU = 4, KC = (PE + 63) / 64;
-        const int wv = tid >> 6, ln = tid & 63;
-        for (int pr0 = wv; pr0 < PE; pr0 += 4 * RU) {
+        const int wv = tid >> 6, ln = tid & 63, nwv = NT >> 6;
+        for (int pr0 = wv; pr0 < PE; pr0 += nwv * RU) {
             int32_t v[RU][KC];
 #pragma unroll
             for (int u = 0; u < RU; u++) {
-                const int pr = pr0 + 4 * u, gr = prow0 + pr;
+                const int pr = pr0 + nwv * u, gr = prow0 + pr;
                 const bool rowok = pr < PE && gr >= 0 && gr <= H;
 #pragma unroll
                 for (int k = 0; k < KC; k++) {
@@ -611,7 +611,7 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
             }
 #pragma unroll
             for (int u = 0; u < RU; u++) {
-                const int pr = pr0 + 4 * u;
+                const int pr = pr0 + nwv * u;
 #pragma unroll
                 for (int k = 0; k < KC; k++) {
                     const int pc = ln + 64 * k;
@@ -632,7 +632,7 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
         const int samples_i = fits ? 1 + (H - lsize) / step : 0;
         const int samples_j = fits ? 1 + (W - lsize) / step : 0;
         const int dm = kMarginMax - lmargin;
-        for (int s = tid; s < T * T; s += 256) {
+        for (int s = tid; s < T * T; s += NT) {
             const int yy = s / T, xx = s - yy * T;
             const int oi = i0 + yy - lmargin, oj = j0 + xx - lmargin;
             float dv = 0.f;
@@ -654,8 +654,8 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
 
 // octave-0 tiles (LDS patch) and the few tiles of octaves >= OG (taps from L1/L2) in ONE grid, so that the long,
 // latency-bound workgroups of the coarse octaves overlap the bulk of the work
-template <int T0>
-__global__ __launch_bounds__(256) void k_hessian_nms_fused(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+template <int T0, int NTH>
+__global__ __launch_bounds__(NTH) void k_hessian_nms_fused(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                            int tiles_x0, int n_tiles0, DetectGeom g_rest, float thr,
                                                            vo_keypoint* __restrict__ kp_base, int cap,
                                                            FrameCounters* __restrict__ cnt, int filter_invalid) {
@@ -671,8 +671,8 @@ __global__ __launch_bounds__(256) void k_hessian_nms_fused(const int32_t* __rest
                                     filter_invalid);
 }
 
-template <int T, int O>
-__global__ __launch_bounds__(256) void k_hessian_nms_lds(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+template <int T, int O, int NTH>
+__global__ __launch_bounds__(NTH) void k_hessian_nms_lds(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                          int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
                                                          FrameCounters* __restrict__ cnt, int filter_invalid) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LdsTileCfg<T, O>::kBytes];
@@ -1765,10 +1765,10 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         g2.tile_base[kNumOctaves] = base2;
         constexpr int T0 = 32, T1 = 24;
         const int tx1 = ((fs.W >> 1) + T1 - 3) / (T1 - 2), ty1 = ((fs.H >> 1) + T1 - 3) / (T1 - 2);
-        hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1>), dim3(tx1 * ty1, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
+        hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1, 512>), dim3(tx1 * ty1, fs.F), dim3(512), 0, ctx->stream, fs.sum, fs.sum_stride(),
                            fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
         const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
-        hipLaunchKernelGGL((k_hessian_nms_fused<T0>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
+        hipLaunchKernelGGL((k_hessian_nms_fused<T0, 256>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
                            fs.sum_stride(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
                            describe ? 1 : 0);
         VO_HIP(hipGetLastError());
