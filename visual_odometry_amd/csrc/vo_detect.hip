@@ -1449,8 +1449,9 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
 }
 
 // WHI: largest window of the class; NW wavefronts per keypoint; a gather covers RB rows x 64/RB columns; UMAX gathers in
-// flight per lane; a strip is G groups of RB rows per wavefront (sampled back to back, then one row pass and one fold).
-template <int WHI, int NW, int RB, int UMAX, int G>
+// flight per lane; a strip is G groups of RB rows per wavefront (sampled back to back, then one row pass and one fold);
+// CH work-queue tickets per atomic.
+template <int WHI, int NW, int RB, int UMAX, int G, int CH>
 __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                             const uint32_t* __restrict__ quad_base,
                                                             const int32_t* __restrict__ sum_base, size_t sum_stride, int H,
@@ -1488,8 +1489,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     // Work queue with a one-keypoint look-ahead: thread 0 draws the NEXT ticket, list entry and keypoint record
     // while the workgroup describes the current one, so the three dependent global round trips (atomic, list,
     // record) are off the critical path of a keypoint.
+    // Tickets are drawn CH at a time: atomics on one counter complete at ~12 ns each on this part, which would
+    // otherwise bound the classes of small windows (130 k keypoints per step).
+    int q_next = 0, q_end = 0;  // thread 0: rest of the chunk of tickets in hand
     if (tid == 0) {
-        const int it = atomicAdd(&cls_cnt[8 + cls], 1);
+        const int it = atomicAdd(&cls_cnt[8 + cls], CH);
+        q_next = it + 1;
+        q_end = it + CH;
         s_q[0] = it;
         if (it < n_items) {
             const int cd = list[it];
@@ -1510,7 +1516,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         const float descriptor_dir = __int_as_float(s_q[5]);  // k_orientation
         const int frame = code / cap, k = code - frame * cap;
         int n_item = 0, n_code = 0;
-        if (tid == 0) n_item = atomicAdd(&cls_cnt[8 + cls], 1);  // look-ahead stage 1: ticket
+        if (tid == 0) {  // look-ahead stage 1: ticket
+            if (q_next < q_end) {
+                n_item = q_next++;
+            } else {
+                n_item = atomicAdd(&cls_cnt[8 + cls], CH);
+                q_next = n_item + 1;
+                q_end = n_item + CH;
+            }
+        }
         const float s = size * 1.2f / 9.0f;
         const int win = (int)((kPatch + 1) * s);
         const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
@@ -1547,6 +1561,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 
         lds_u8* wbase = (lds_u8*)s_win + wave * (WR * kPitch);
         int* s_rowi = reinterpret_cast<int*>(s_rowv);
+        const int myrow = lane / (kPatch + 1), mycell = lane - myrow * (kPatch + 1);  // row pass: lane = (row mod 3, cell)
+        CellTab myct = {};
+        if (!area_fast) myct = s_cell[mycell];
         // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane)
         float vacc = 0.f;
         int viacc = 0, dy = 0, left = iscale;
@@ -1607,35 +1624,37 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                 // INTER_AREA row pass: one (row, destination cell) per lane, the cell's pixels in table order
                 const int nrw = min(WR, win - wrow0);
                 const int nub = (int)scale + 1;
-                for (int it = lane; it < nrw * (kPatch + 1); it += 64) {
-                    const int rr = it / (kPatch + 1), cell = it - rr * (kPatch + 1);
-                    const lds_u8* p = wbase + rr * kPitch;
-                    const int o = (sidx * RS + wave * WR + rr) * (kPatch + 1) + cell;
-                    if (area_fast) {
+                if (area_fast) {
+                    for (int it = lane; it < nrw * (kPatch + 1); it += 64) {
+                        const int rr = it / (kPatch + 1), cell = it - rr * (kPatch + 1);
+                        const lds_u8* p = wbase + rr * kPitch;
                         int tot = 0;
                         for (int q = cell * iscale; q < (cell + 1) * iscale; q++) tot += p[q];
-                        s_rowi[o] = tot;
-                    } else {
-                        const CellTab ct = s_cell[cell];
-                        const int n = ct.sx2 - ct.sx1;  // full-weight pixels of this cell: at most nub, the same bound in every lane
-                        const int ph = p[max(ct.sx1 - 1, 0)], pt = p[ct.sx2];
-                        const lds_u8* pm = p + ct.sx1;
+                        s_rowi[(sidx * RS + wave * WR + rr) * (kPatch + 1) + cell] = tot;
+                    }
+                } else if (lane < 3 * (kPatch + 1)) {
+                    // lane = (row mod 3, cell): the cell's table entry stays in registers for the whole keypoint
+                    const int n = myct.sx2 - myct.sx1;  // full-weight pixels of this cell: at most nub, the same bound in every lane
+                    for (int rr = myrow; rr < nrw; rr += 3) {
+                        const lds_u8* p = wbase + rr * kPitch;
+                        const int ph = p[max(myct.sx1 - 1, 0)], pt = p[myct.sx2];
+                        const lds_u8* pm = p + myct.sx1;
                         float acc = 0.f;
-                        if (ct.has_head) acc += (float)ph * ct.a_head;
+                        if (myct.has_head) acc += (float)ph * myct.a_head;
                         // four byte reads in flight per step; the adds stay in pixel order, lanes past their own count keep acc
                         for (int k0 = 0; k0 < nub; k0 += 4) {
                             const int v0 = pm[k0], v1 = pm[k0 + 1], v2 = pm[k0 + 2], v3 = pm[k0 + 3];
-                            const float a0 = acc + (float)v0 * ct.a_mid;
+                            const float a0 = acc + (float)v0 * myct.a_mid;
                             acc = k0 < n ? a0 : acc;
-                            const float a1 = acc + (float)v1 * ct.a_mid;
+                            const float a1 = acc + (float)v1 * myct.a_mid;
                             acc = k0 + 1 < n ? a1 : acc;
-                            const float a2 = acc + (float)v2 * ct.a_mid;
+                            const float a2 = acc + (float)v2 * myct.a_mid;
                             acc = k0 + 2 < n ? a2 : acc;
-                            const float a3 = acc + (float)v3 * ct.a_mid;
+                            const float a3 = acc + (float)v3 * myct.a_mid;
                             acc = k0 + 3 < n ? a3 : acc;
                         }
-                        if (ct.has_tail) acc += (float)pt * ct.a_tail;
-                        s_rowv[o] = acc;
+                        if (myct.has_tail) acc += (float)pt * myct.a_tail;
+                        s_rowv[(sidx * RS + wave * WR + rr) * (kPatch + 1) + mycell] = acc;
                     }
                 }
             }
@@ -1793,15 +1812,15 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
                                fs.W, fs.kp, fs.cap, fs.cnt);
             hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                                fs.H, fs.W, fs.quad);
-#define LAUNCH_TILED(HI, NW, RB, UMAX, G, CLS, GRID)                                                                           \
-    hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB, UMAX, G>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img, fs.img_stride(), \
+#define LAUNCH_TILED(HI, NW, RB, UMAX, G, CH, CLS, GRID)                                                                           \
+    hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB, UMAX, G, CH>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img, fs.img_stride(), \
                        fs.quad, fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, \
                        CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe)
             // heaviest class first so that its long keypoints overlap the many short ones that follow
-            LAUNCH_TILED(kBigWin, 4, 8, 8, 1, 3, 768);
-            LAUNCH_TILED(kMidWin, 4, 8, 8, 1, 2, 1280);
-            LAUNCH_TILED(kSmallWin, 1, 8, 8, 4, 1, 5120);
-            LAUNCH_TILED(64, 1, 8, 4, 4, 0, 5120);
+            LAUNCH_TILED(kBigWin, 4, 8, 8, 1, 1, 3, 768);
+            LAUNCH_TILED(kMidWin, 4, 8, 8, 1, 2, 2, 1280);
+            LAUNCH_TILED(kSmallWin, 1, 8, 8, 4, 4, 1, 5120);
+            LAUNCH_TILED(64, 1, 8, 4, 4, 8, 0, 5120);
 #undef LAUNCH_TILED
             // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
             hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.sum,
