@@ -31,7 +31,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=16, help="frame pairs per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="frame pairs per step per GPU (resident in HBM; ~75 MB per pair)")
     ap.add_argument("--scenes", type=int, default=4, help="distinct synthetic pairs per GPU (replicated to fill the batch)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=6)
@@ -88,15 +88,11 @@ def main():
         dt = float(tmax.item())
 
     # result records of this rank's pairs; the gather of these records is the only collective of the job
+    from visual_odometry_amd import shard
+
     outs = [batch.get(i) for i in range(args.batch)]
-    rec = torch.tensor([[o.status, o.n_kp1, o.n_kp2, o.n_match, o.n_inl, o.n_good, o.n_world, o.success] for o in outs],
-                       dtype=torch.int32, device="cuda")
-    if world > 1:
-        allrec = [torch.empty_like(rec) for _ in range(world)]
-        dist.all_gather(allrec, rec)
-        rec_all = torch.cat(allrec).cpu().numpy()
-    else:
-        rec_all = rec.cpu().numpy()
+    rec_local = shard.pack_records(outs)
+    rec_all = shard.gather_records(rec_local, args.batch * world, rank, world, device="cuda" if world > 1 else "cpu")
 
     # per-stage device time of one more pass (HIP events on the library's stream)
     ctx.profile_enable(True)
@@ -109,29 +105,48 @@ def main():
     ctx.profile_enable(False)
 
     if rank == 0:
+        assert rec_all.shape[0] == args.batch * world
         kp = float(rec_all[:, 1:3].mean())
         stage_ms = {k: v[0] / nprof for k, v in prof.items()}
-        launches = {k: v[1] // nprof for k, v in prof.items()}
         frames = 2 * args.batch
         S = layer_samples(H, W)
         I = 4 * (H + 1) * (W + 1)
-        # ALGORITHMIC bytes / flops per launch (SURVEY 8d per-frame figures x frames per launch)
+        # share of the Hessian samples per octave, and of the keypoints / window samples per descriptor class
+        S_oct = [5 * (H >> o) * (W >> o) for o in range(4)]
+        kp1, _ = ctx.detect_describe(scenes[0].img1)
+        win = (21 * (kp1["size"].astype(np.float32) * np.float32(1.2) / np.float32(9.0))).astype(np.int64)
+        cls_share = {}
+        for name, lo, hi in (("describe_w64", 0, 64), ("describe_w128", 64, 128), ("describe_w320", 128, 320), ("describe_w768", 320, 768)):
+            m = (win > lo) & (win <= hi)
+            cls_share[name] = float(m.mean())
+        # ALGORITHMIC bytes / flops per launch (SURVEY 8d per-frame figures x frames per launch; per-kernel shares of them)
+        hess_bytes = lambda So: frames * ((I + 8 * So) + (4 * So + 28 * kp * So / S))
         alg = {
             "integral": ("hbm", frames * (H * W + I)),
-            "hessian_nms": ("hbm", frames * ((I + 8 * S) + (4 * S + 28 * kp))),
-            "describe": ("hbm", frames * (H * W + I + 256 * kp)),
+            "hessian_oct0_23": ("hbm", hess_bytes(S_oct[0] + S_oct[2] + S_oct[3])),
+            "hessian_oct1": ("hbm", hess_bytes(S_oct[1])),
             "match_mfma": ("mfma", args.batch * 2 * 64 * float(rec_all[:, 1].mean()) * float(rec_all[:, 2].mean())),
         }
+        for name, sh in cls_share.items():
+            alg[name] = ("hbm", frames * (sh * (H * W + I) + 256 * kp * sh))
+
+        def roof(name):
+            bound, work = alg[name]
+            dur_s = stage_ms[name] / 1e3
+            if bound == "hbm":
+                achieved, peak, unit = work / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
+            else:
+                achieved, peak, unit = work / dur_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
+            return {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
+                    "frac": round(achieved / peak, 5), "traffic": None, "launch_ms": round(dur_s * 1e3, 4),
+                    "algorithmic_per_launch": work}
+
         dom = max(alg, key=lambda k: stage_ms.get(k, 0.0))
-        bound, work = alg[dom]
-        dur_s = stage_ms[dom] / 1e3 / max(launches[dom] if dom != "describe" else 1, 1)
-        if bound == "hbm":
-            achieved, peak, unit = work / dur_s / 1e9, HBM_PEAK_GBS, "GB/s"
-        else:
-            achieved, peak, unit = work / dur_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
-        roofline = {"kernel": dom, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 5), "traffic": None,
-                    "launch_ms": round(dur_s * 1e3, 4), "algorithmic_per_launch": work}
+        roofline = roof(dom)
+        # The descriptor and Hessian kernels are bound by VALU issue and the texture addresser's gather rate, not by HBM
+        # (PMC evidence under profiles/): their HBM fraction is small by construction.
+        roofline["note"] = "dominant kernel by device time; descriptor/Hessian kernels are VALU-issue / gather bound, see roofline_all and DESIGN.md"
+        roofline_all = [roof(k) for k in sorted(alg, key=lambda k: -stage_ms.get(k, 0.0))]
 
         cpu = None
         if not args.no_cpu_baseline:
@@ -172,6 +187,7 @@ def main():
                        "pairs_with_pose": int(rec_all[:, 7].sum()), "pairs_total": int(len(rec_all)),
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "roofline": roofline,
+            "roofline_all": roofline_all,
             "cpu_baseline": cpu,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
         }

@@ -11,7 +11,7 @@ int main() {
     std::vector<uint8_t> a((size_t)H * W, 128), b((size_t)H * W, 128);
     unsigned s = 12345;
     auto rnd = [&]() { s = s * 1664525u + 1013904223u; return (s >> 8) & 0xffff; };
-    for (int k = 0; k < 400; k++) {  // textured features at different depths: camera moves along x, disparity 10..40 px
+    for (int k = 0; k < 220; k++) {  // textured features at different depths: camera moves along x, disparity 10..40 px
         const int cx = 40 + rnd() % (W - 100), cy = 40 + rnd() % (H - 80);
         const int disp = 10 + rnd() % 31;
         for (int part = 0; part < 4; part++) {  // a spot and three random satellites give every feature an orientation

@@ -89,8 +89,9 @@ static void resolve_timers(vo_ctx* ctx) {
     }
 }
 
-static const char* kStageNames[ST_COUNT] = {"integral",      "hessian_nms",        "sort",          "describe",
-                                            "match_prep",    "match_mfma",         "match_select",  "ransac_sample",
+static const char* kStageNames[ST_COUNT] = {"integral",      "hessian_oct1",  "hessian_oct0_23",    "sort",          "orientation",
+                                            "describe_prep", "describe_w768", "describe_w320",      "describe_w128", "describe_w64",
+                                            "describe_seq",  "match_prep",    "match_mfma",         "match_select",  "ransac_sample",
                                             "ransac_solve_score", "ransac_select", "pose",          "triangulate"};
 
 extern "C" int vo_stage_count(void) { return ST_COUNT; }

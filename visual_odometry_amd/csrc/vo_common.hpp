@@ -90,9 +90,16 @@ struct PairState {
 // ---------------------------------------------------------------- profiling stages
 enum Stage {
     ST_INTEGRAL = 0,
-    ST_HESSIAN_NMS,
+    ST_HESSIAN_OCT1,    // k_hessian_nms_lds<24, 1>
+    ST_HESSIAN_OCT0,    // k_hessian_nms_fused (octave 0 from LDS + octaves 2-3)
     ST_SORT,
-    ST_DESCRIBE,
+    ST_ORIENTATION,
+    ST_DESC_PREP,       // k_quads + k_classify
+    ST_DESC_W768,       // k_describe_tiled, one stage per window class
+    ST_DESC_W320,
+    ST_DESC_W128,
+    ST_DESC_W64,
+    ST_DESC_SEQ,        // k_describe: sequential-walk fallback list
     ST_MATCH_PREP,
     ST_MATCH_MFMA,
     ST_MATCH_SELECT,

@@ -1771,7 +1771,6 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
     }
     g.tile_base[kNumOctaves] = base;
     {
-        StageScope sc(ctx, ST_HESSIAN_NMS);
         // octaves 0 and 1 (94 % of the samples): integral patch staged in LDS.  Octaves 2-3: taps straight from L1/L2
         // (a patch would be 2-4x the tile's own taps); their few long workgroups ride in the octave-0 grid.
         DetectGeom g2 = g;
@@ -1784,8 +1783,11 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         g2.tile_base[kNumOctaves] = base2;
         constexpr int T0 = 32, T1 = 24;
         const int tx1 = ((fs.W >> 1) + T1 - 3) / (T1 - 2), ty1 = ((fs.H >> 1) + T1 - 3) / (T1 - 2);
+        StageScope* sc1 = new StageScope(ctx, ST_HESSIAN_OCT1);
         hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1, 512>), dim3(tx1 * ty1, fs.F), dim3(512), 0, ctx->stream, fs.sum, fs.sum_stride(),
                            fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
+        delete sc1;
+        StageScope sc0(ctx, ST_HESSIAN_OCT0);
         const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
         hipLaunchKernelGGL((k_hessian_nms_fused<T0, 256>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
                            fs.sum_stride(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
@@ -1802,29 +1804,40 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         VO_HIP(hipGetLastError());
     }
     {
-        StageScope sc(ctx, ST_DESCRIBE);
         float* d = describe ? fs.desc : nullptr;
         if (describe) {
             const size_t ls = (size_t)fs.F * fs.cap;
-            hipLaunchKernelGGL(k_classify, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt,
-                               fs.cls_list, ls, fs.cls_cnt);
-            hipLaunchKernelGGL(k_orientation, dim3((fs.cap + 3) / 4, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(), fs.H,
-                               fs.W, fs.kp, fs.cap, fs.cnt);
-            hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
-                               fs.H, fs.W, fs.quad);
-#define LAUNCH_TILED(HI, NW, RB, UMAX, G, CH, CLS, GRID)                                                                           \
-    hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB, UMAX, G, CH>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img, fs.img_stride(), \
-                       fs.quad, fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, \
-                       CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe)
+            {
+                StageScope sc(ctx, ST_ORIENTATION);
+                hipLaunchKernelGGL(k_orientation, dim3((fs.cap + 3) / 4, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
+                                   fs.H, fs.W, fs.kp, fs.cap, fs.cnt);
+            }
+            {
+                StageScope sc(ctx, ST_DESC_PREP);
+                hipLaunchKernelGGL(k_classify, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt,
+                                   fs.cls_list, ls, fs.cls_cnt);
+                hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img,
+                                   fs.img_stride(), fs.H, fs.W, fs.quad);
+            }
+#define LAUNCH_TILED(STAGE, HI, NW, RB, UMAX, G, CH, CLS, GRID)                                                                     \
+    {                                                                                                                              \
+        StageScope sc(ctx, STAGE);                                                                                                 \
+        hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB, UMAX, G, CH>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img,          \
+                           fs.img_stride(), fs.quad, fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap,                         \
+                           fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe); \
+    }
             // heaviest class first so that its long keypoints overlap the many short ones that follow
-            LAUNCH_TILED(kBigWin, 4, 8, 8, 1, 1, 3, 768);
-            LAUNCH_TILED(kMidWin, 4, 8, 8, 1, 2, 2, 1280);
-            LAUNCH_TILED(kSmallWin, 1, 8, 8, 4, 4, 1, 5120);
-            LAUNCH_TILED(64, 1, 8, 4, 4, 8, 0, 5120);
+            LAUNCH_TILED(ST_DESC_W768, kBigWin, 4, 8, 8, 1, 1, 3, 768);
+            LAUNCH_TILED(ST_DESC_W320, kMidWin, 4, 8, 8, 1, 2, 2, 1280);
+            LAUNCH_TILED(ST_DESC_W128, kSmallWin, 1, 8, 8, 4, 4, 1, 5120);
+            LAUNCH_TILED(ST_DESC_W64, 64, 1, 8, 4, 4, 8, 0, 5120);
 #undef LAUNCH_TILED
-            // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
-            hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.sum,
-                               fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4);
+            {
+                // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
+                StageScope sc(ctx, ST_DESC_SEQ);
+                hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                                   fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4);
+            }
             VO_HIP(hipGetLastError());
         }
     }
