@@ -68,6 +68,56 @@ def test_descriptors_exact(ctx, shape, nb, seed):
         assert len(bad) == 0, (len(bad), len(k), bad[:10], np.abs(d - rd).max())
 
 
+def _window_sizes(k):
+    s = k["size"].astype(np.float32) * np.float32(1.2) / np.float32(9.0)
+    return (np.float32(21) * s).astype(np.int64)
+
+
+def test_descriptors_exact_1080p_all_window_classes(ctx):
+    """BASELINE configs[1] frame (8k keypoints): every descriptor window class of the tiled sampler (<= 64, <= 128,
+    <= 320, <= 768 px), the LDS-staged Hessian octaves and the coarse octaves, bit for bit against the oracle."""
+    sc = synth.scene_c2(2002)
+    k, d = ctx.detect_describe(sc.img1)
+    rk, rd = O.detect_describe(sc.img1)
+    _assert_kps_equal(k, rk)
+    win = _window_sizes(k)
+    for lo, hi in ((0, 64), (64, 128), (128, 320), (320, 768)):
+        assert ((win > lo) & (win <= hi)).sum() > 20, (lo, hi)
+    assert set(np.unique(k["octave"])) == {0, 1, 2, 3}
+    assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+    bad = np.flatnonzero((d.view(np.uint32) != rd.view(np.uint32)).any(axis=1))
+    assert len(bad) == 0, (len(bad), len(k), bad[:10], win[bad[:10]])
+
+
+def test_descriptors_exact_4k_frame(ctx):
+    """BASELINE configs[3] frame size (3840 x 2160): coordinates above 2^11, the largest integral sums."""
+    sc = synth.blob_scene(2160, 3840, synth.K_4K, 2500, 4004, depth=(6.5, 8.5), baseline=0.3, sigma_px=(2.0, 9.0))
+    k, d = ctx.detect_describe(sc.img1, cap=32768)
+    rk, rd = O.detect_describe(sc.img1)
+    _assert_kps_equal(k, rk)
+    assert len(k) > 2000
+    assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+    assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+
+
+def test_keypoints_at_frame_border_use_clamped_sampler(ctx):
+    """Bright structure hard against the frame edges: windows that leave the frame take the generic (clamped
+    nearest-pixel) sampler; a frame smaller than the largest filters exercises the empty coarse octaves."""
+    rng = np.random.default_rng(99)
+    img = np.full((160, 200), 100, np.uint8)
+    yy, xx = np.mgrid[0:160, 0:200]
+    for _ in range(60):
+        cy, cx = rng.integers(0, 160), rng.integers(0, 200)
+        sg = rng.uniform(1.5, 6.0)
+        img = np.clip(img + rng.uniform(-80, 120) * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sg * sg)), 0, 255).astype(np.uint8)
+    k, d = ctx.detect_describe(img)
+    rk, rd = O.detect_describe(img)
+    _assert_kps_equal(k, rk)
+    assert len(k) > 10
+    assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+    assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+
+
 def test_uniform_image_has_no_keypoints(ctx):
     img = np.full((200, 300), 77, np.uint8)
     k, d = ctx.detect_describe(img)
