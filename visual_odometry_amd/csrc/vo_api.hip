@@ -689,6 +689,12 @@ extern "C" int vo_batch_create(vo_ctx* ctx, int n_pairs, int rows, int cols, vo_
         vo_batch_destroy(b);
         return st;
     }
+    if (hipHostMalloc((void**)&b->h_stage, (size_t)2 * n_pairs * rows * cols, hipHostMallocDefault) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming) != hipSuccess) {
+        vo_set_hip_error("hipHostMalloc/hipEventCreate", hipGetLastError(), __FILE__, __LINE__);
+        vo_batch_destroy(b);
+        return VO_ERR_HIP;
+    }
     b->h_state.resize(n_pairs);
     b->h_cnt.resize(2 * n_pairs);
     for (auto& S : b->h_state) init_state(S, 0, nullptr);
@@ -702,6 +708,8 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
     hipStreamSynchronize(b->ctx->stream);
     vo_frameset_free(b->fs);
     vo_pairset_free(b->ps);
+    if (b->h_stage) hipHostFree(b->h_stage);
+    if (b->ev_upload) hipEventDestroy(b->ev_upload);
     delete b;
 }
 
@@ -711,8 +719,24 @@ extern "C" int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, siz
     VO_TRY(check_image(img1, b->rows, b->cols, step1));
     VO_TRY(check_image(img2, b->rows, b->cols, step2));
     VO_HIP(hipSetDevice(b->ctx->device));
-    VO_TRY(upload_frame(b->ctx, b->fs, 2 * pair, img1, step1));
-    VO_TRY(upload_frame(b->ctx, b->fs, 2 * pair + 1, img2, step2));
+    // the caller's buffers may be pageable and may be reused as soon as this returns: the frames go through the batch's
+    // pinned staging copy, the H2D transfer itself is asynchronous on the context's stream
+    if (b->upload_pending) {
+        VO_HIP(hipEventSynchronize(b->ev_upload));  // staging slots of the previous step are free again
+        b->upload_pending = false;
+    }
+    const size_t fbytes = (size_t)b->rows * b->cols;
+    const uint8_t* src[2] = {img1, img2};
+    const size_t steps[2] = {step1, step2};
+    for (int v = 0; v < 2; v++) {
+        uint8_t* dst = b->h_stage + (size_t)(2 * pair + v) * fbytes;
+        if (steps[v] == (size_t)b->cols)
+            std::memcpy(dst, src[v], fbytes);
+        else
+            for (int r = 0; r < b->rows; r++) std::memcpy(dst + (size_t)r * b->cols, src[v] + (size_t)r * steps[v], b->cols);
+        VO_HIP(hipMemcpyAsync(b->fs.img + (size_t)(2 * pair + v) * b->fs.img_stride(), dst, fbytes, hipMemcpyHostToDevice,
+                              b->ctx->stream));
+    }
     init_state(b->h_state[pair], 0, K);
     b->state_dirty = true;
     return VO_OK;
@@ -722,6 +746,10 @@ extern "C" int vo_batch_run(vo_batch* b) {
     if (!b) return VO_ERR_INVALID_ARG;
     vo_ctx* ctx = b->ctx;
     VO_HIP(hipSetDevice(ctx->device));
+    if (b->state_dirty) {  // frames were uploaded since the last run
+        VO_HIP(hipEventRecord(b->ev_upload, ctx->stream));
+        b->upload_pending = true;
+    }
     VO_TRY(reset_counters(ctx, b->fs));
     if (b->state_dirty) {
         // K / initial pose of every pair; the kernels reset everything else themselves

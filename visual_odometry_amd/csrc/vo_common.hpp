@@ -188,6 +188,9 @@ struct vo_batch {
     std::vector<PairState> h_state, h_init;  // host mirrors (results / initial K and pose)
     std::vector<FrameCounters> h_cnt;
     bool state_dirty = true, fetched = false;
+    uint8_t* h_stage = nullptr;      // pinned staging copy of the frames: vo_batch_set_pair returns before the H2D copy ends
+    hipEvent_t ev_upload = nullptr;  // recorded after the latest frame upload
+    bool upload_pending = false;
 };
 
 // ---------------------------------------------------------------- helpers (vo_api.cpp)
