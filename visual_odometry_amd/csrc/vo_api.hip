@@ -150,7 +150,8 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.nrm, (size_t)F * cap));
     VO_TRY(dalloc(fs.cnt, (size_t)F));
     VO_TRY(dalloc(fs.cls_list, (size_t)5 * F * cap));
-    VO_TRY(dalloc(fs.cls_cnt, (size_t)16));
+    VO_TRY(dalloc(fs.cls_cnt, (size_t)kClsCntInts));
+    VO_TRY(dalloc(fs.cls_hist, (size_t)4 * F * (((W + 255) / 256) * ((H + 255) / 256)) + 4));
     VO_HIP(hipMemset(fs.rank, 0, (size_t)F * cap * sizeof(int)));
     VO_HIP(hipMemset(fs.cnt, 0, (size_t)F * sizeof(FrameCounters)));
     return VO_OK;
@@ -170,6 +171,7 @@ void vo_frameset_free(FrameSet& fs) {
     dfree(fs.cnt);
     dfree(fs.cls_list);
     dfree(fs.cls_cnt);
+    dfree(fs.cls_hist);
     fs.F = fs.H = fs.W = fs.cap = 0;
 }
 
@@ -257,7 +259,8 @@ static int upload_frame(vo_ctx* ctx, FrameSet& fs, int frame, const uint8_t* img
 
 static int reset_counters(vo_ctx* ctx, FrameSet& fs) {
     VO_HIP(hipMemsetAsync(fs.cnt, 0, (size_t)fs.F * sizeof(FrameCounters), ctx->stream));
-    VO_HIP(hipMemsetAsync(fs.cls_cnt, 0, 16 * sizeof(int), ctx->stream));
+    VO_HIP(hipMemsetAsync(fs.cls_cnt, 0, kClsCntInts * sizeof(int), ctx->stream));
+    VO_HIP(hipMemsetAsync(fs.cls_hist, 0, ((size_t)4 * fs.F * fs.nbins() + 4) * sizeof(int), ctx->stream));
     return VO_OK;
 }
 

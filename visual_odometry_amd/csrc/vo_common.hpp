@@ -118,6 +118,8 @@ struct StageTimer {
 };
 
 // ---------------------------------------------------------------- device buffers
+constexpr int kClsCntInts = 64;
+
 struct FrameSet {
     int F = 0, H = 0, W = 0, cap = 0;
     uint8_t* img = nullptr;      // [F][H][W]
@@ -132,7 +134,9 @@ struct FrameSet {
     float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
     FrameCounters* cnt = nullptr;   // [F]
     int* cls_list = nullptr;        // [5][F*cap] keypoints (frame*cap + k) of each descriptor window class; list 4 = sequential-walk fallback
-    int* cls_cnt = nullptr;         // [16] list lengths [0..4], work-queue tickets [8..12]
+    int* cls_cnt = nullptr;         // [kClsCntInts] list lengths [0..4]; work-queue tickets [8 + 8*cls + segment]
+    int* cls_hist = nullptr;        // [4][F*nbins] keypoints per (class, frame, 256-px tile): counting sort of the class lists
+    int nbins() const { return ((W + 255) / 256) * ((H + 255) / 256); }
     size_t img_stride() const { return (size_t)H * W; }
     size_t sum_stride() const { return (size_t)(H + 1) * (W + 1); }
 };

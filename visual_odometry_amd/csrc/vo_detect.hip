@@ -1072,7 +1072,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     // workgroup leaves as soon as its ticket is past the end of the list
     for (;;) {
     __syncthreads();  // previous keypoint's LDS is no longer read
-    if (tid == 0) s_item = atomicAdd(&cls_cnt[8 + cls], 1);
+    if (tid == 0) s_item = atomicAdd(&cls_cnt[8 + 8 * cls], 1);
     __syncthreads();
     const int item = s_item;
     if (item >= n_items) break;
@@ -1489,13 +1489,28 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     // Work queue with a one-keypoint look-ahead: thread 0 draws the NEXT ticket, list entry and keypoint record
     // while the workgroup describes the current one, so the three dependent global round trips (atomic, list,
     // record) are off the critical path of a keypoint.
-    // Tickets are drawn CH at a time: atomics on one counter complete at ~12 ns each on this part, which would
-    // otherwise bound the classes of small windows (130 k keypoints per step).
-    int q_next = 0, q_end = 0;  // thread 0: rest of the chunk of tickets in hand
+    // Tickets are drawn CH at a time (atomics on one counter complete at ~12 ns each on this part, which would otherwise
+    // bound the classes of small windows).  The list is cut into 8 contiguous segments with a counter each; a workgroup
+    // starts in segment blockIdx.x % 8 - the label shared by the workgroups of one XCD - and moves on to the other
+    // segments when its own is empty.
+    int q_next = 0, q_end = 0, q_seg = blockIdx.x & 7, q_tried = 0;  // thread 0 only
+    auto draw = [&]() -> int {
+        if (q_next < q_end) return q_next++;
+        while (q_tried < 8) {
+            const int lo = (int)((long long)n_items * q_seg >> 3), hi = (int)((long long)n_items * (q_seg + 1) >> 3);
+            const int t = lo + atomicAdd(&cls_cnt[8 + 8 * cls + q_seg], CH);
+            if (t < hi) {
+                q_next = t + 1;
+                q_end = min(t + CH, hi);
+                return t;
+            }
+            q_seg = (q_seg + 1) & 7;
+            q_tried++;
+        }
+        return n_items;
+    };
     if (tid == 0) {
-        const int it = atomicAdd(&cls_cnt[8 + cls], CH);
-        q_next = it + 1;
-        q_end = it + CH;
+        const int it = draw();
         s_q[0] = it;
         if (it < n_items) {
             const int cd = list[it];
@@ -1516,15 +1531,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         const float descriptor_dir = __int_as_float(s_q[5]);  // k_orientation
         const int frame = code / cap, k = code - frame * cap;
         int n_item = 0, n_code = 0;
-        if (tid == 0) {  // look-ahead stage 1: ticket
-            if (q_next < q_end) {
-                n_item = q_next++;
-            } else {
-                n_item = atomicAdd(&cls_cnt[8 + cls], CH);
-                q_next = n_item + 1;
-                q_end = n_item + CH;
-            }
-        }
+        if (tid == 0) n_item = draw();  // look-ahead stage 1: ticket
         const float s = size * 1.2f / 9.0f;
         const int win = (int)((kPatch + 1) * s);
         const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
@@ -1727,30 +1734,66 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     }
 }
 
-// window class of every keypoint -> per-class work lists (order inside a list is irrelevant)
-__global__ __launch_bounds__(256) void k_classify(const vo_keypoint* __restrict__ kp_base, int cap,
-                                                  const FrameCounters* __restrict__ cnt, int* __restrict__ lists,
-                                                  size_t list_stride, int* __restrict__ cls_cnt) {
+// Window class of every keypoint -> per-class work lists, counting-sorted by (frame, 256-px tile).  Keypoints that
+// are close in a list are close in the frame, and the descriptor kernels hand contiguous list segments to the
+// workgroups of one XCD: the windows those workgroups sample overlap, so the footprint image is served from that
+// XCD's L2 instead of being re-fetched over the fabric for every keypoint (the order inside a list is otherwise
+// irrelevant: every keypoint's result is independent of it).
+__device__ __forceinline__ int classify_key(const vo_keypoint& kp, int frame, int W, int nbins, int* cls) {
+    const float s = kp.size * 1.2f / 9.0f;
+    const int win = (int)((kPatch + 1) * s);
+    *cls = win <= 64 ? 0 : (win <= kSmallWin ? 1 : (win <= kMidWin ? 2 : 3));
+    const int bx = min(max((int)kp.x, 0), W - 1) >> 8, by = max((int)kp.y, 0) >> 8;
+    const int bins_x = (W + 255) >> 8;
+    return frame * nbins + min(by * bins_x + bx, nbins - 1);
+}
+
+__global__ __launch_bounds__(256) void k_classify_count(const vo_keypoint* __restrict__ kp_base, int cap,
+                                                        const FrameCounters* __restrict__ cnt, int W, int nbins, int nkeys,
+                                                        int* __restrict__ hist) {
     const int frame = blockIdx.y;
-    const int n = min(cnt[frame].n_raw, cap);
     const int k = blockIdx.x * 256 + threadIdx.x;
-    int cls = -1;
-    if (k < n) {
-        const float s = kp_base[(size_t)frame * cap + k].size * 1.2f / 9.0f;
-        const int win = (int)((kPatch + 1) * s);
-        cls = win <= 64 ? 0 : (win <= kSmallWin ? 1 : (win <= kMidWin ? 2 : 3));
+    if (k >= min(cnt[frame].n_raw, cap)) return;
+    int cls;
+    const int key = classify_key(kp_base[(size_t)frame * cap + k], frame, W, nbins, &cls);
+    atomicAdd(&hist[cls * nkeys + key], 1);
+}
+
+// one workgroup per class: exclusive scan of the histogram in place (it becomes the scatter cursor), total -> cls_cnt
+__global__ __launch_bounds__(1024) void k_classify_scan(int nkeys, int* __restrict__ hist, int* __restrict__ cls_cnt) {
+    __shared__ int s_part[1024];
+    int* h = hist + (size_t)blockIdx.x * nkeys;
+    const int tid = threadIdx.x;
+    const int per = (nkeys + 1023) / 1024;
+    const int lo = min(tid * per, nkeys), hi = min(lo + per, nkeys);
+    int tot = 0;
+    for (int i = lo; i < hi; i++) tot += h[i];
+    s_part[tid] = tot;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        const int v = tid >= d ? s_part[tid - d] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
     }
-    const int lane = threadIdx.x & 63;
-#pragma unroll
-    for (int c = 0; c < 4; c++) {
-        const unsigned long long m = __ballot(cls == c);
-        if (m) {
-            int base = 0;
-            if (lane == 0) base = atomicAdd(&cls_cnt[c], __popcll(m));
-            base = __shfl(base, 0, 64);
-            if (cls == c) lists[c * list_stride + base + __popcll(m & ((1ull << lane) - 1ull))] = frame * cap + k;
-        }
+    int run = s_part[tid] - tot;
+    for (int i = lo; i < hi; i++) {
+        const int c = h[i];
+        h[i] = run;
+        run += c;
     }
+    if (tid == 1023) cls_cnt[blockIdx.x] = s_part[1023];
+}
+
+__global__ __launch_bounds__(256) void k_classify_scatter(const vo_keypoint* __restrict__ kp_base, int cap,
+                                                          const FrameCounters* __restrict__ cnt, int W, int nbins, int nkeys,
+                                                          int* __restrict__ hist, int* __restrict__ lists, size_t list_stride) {
+    const int frame = blockIdx.y;
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= min(cnt[frame].n_raw, cap)) return;
+    int cls;
+    const int key = classify_key(kp_base[(size_t)frame * cap + k], frame, W, nbins, &cls);
+    lists[cls * list_stride + atomicAdd(&hist[cls * nkeys + key], 1)] = frame * cap + k;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1814,8 +1857,13 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             }
             {
                 StageScope sc(ctx, ST_DESC_PREP);
-                hipLaunchKernelGGL(k_classify, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt,
-                                   fs.cls_list, ls, fs.cls_cnt);
+                const int nbins = fs.nbins(), nkeys = fs.F * nbins;
+                const dim3 gk((fs.cap + 255) / 256, fs.F);
+                hipLaunchKernelGGL(k_classify_count, gk, dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt, fs.W, nbins, nkeys,
+                                   fs.cls_hist);
+                hipLaunchKernelGGL(k_classify_scan, dim3(4), dim3(1024), 0, ctx->stream, nkeys, fs.cls_hist, fs.cls_cnt);
+                hipLaunchKernelGGL(k_classify_scatter, gk, dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt, fs.W, nbins, nkeys,
+                                   fs.cls_hist, fs.cls_list, ls);
                 hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img,
                                    fs.img_stride(), fs.H, fs.W, fs.quad);
             }
