@@ -164,6 +164,22 @@ def main():
         for name, sh in cls_share.items():
             alg[name] = ("hbm", frames * (sh * (H * W + I) + 256 * kp * sh))
 
+        # HBM-side traffic per launch: PMC counters cannot be read from inside this process; the figures come from the
+        # committed rocprofv3 --pmc passes of this same command (profiles/) and apply to the default
+        # workload only
+        traffic = {}
+        tpath = os.path.join(ROOT, "profiles", "r01_d_hbm_traffic.json")
+        if args.batch == 64 and os.path.exists(tpath):
+            prefix = {"describe_w64": "k_describe_tiled<64,", "describe_w128": "k_describe_tiled<128,",
+                      "describe_w320": "k_describe_tiled<320,", "describe_w768": "k_describe_tiled<768,",
+                      "hessian_oct0_23": "k_hessian_nms_fused<", "hessian_oct1": "k_hessian_nms_lds<", "integral": "k_integral<",
+                      "match_mfma": "k_match_mfma"}
+            tj = json.load(open(tpath))
+            for st, pf in prefix.items():
+                for kname, v in tj.items():
+                    if kname.startswith(pf):
+                        traffic[st] = v["hbm_bytes_per_launch"]
+
         def roof(name):
             bound, work = alg[name]
             dur_s = stage_ms[name] / 1e3
@@ -172,7 +188,7 @@ def main():
             else:
                 achieved, peak, unit = work / dur_s / 1e12, MFMA_F32_PEAK_TFLOPS, "TFLOP/s"
             return {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                    "frac": round(achieved / peak, 5), "traffic": None, "launch_ms": round(dur_s * 1e3, 4),
+                    "frac": round(achieved / peak, 5), "traffic": traffic.get(name), "launch_ms": round(dur_s * 1e3, 4),
                     "algorithmic_per_launch": work}
 
         dom = max(alg, key=lambda k: stage_ms.get(k, 0.0))
