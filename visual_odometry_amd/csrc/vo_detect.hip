@@ -739,6 +739,63 @@ __global__ __launch_bounds__(256) void k_scatter(const vo_keypoint* __restrict__
     if (r < n) out_base[o + r] = kp_base[o + i];
 }
 
+// a4, up to 16384 keypoints per frame: bitonic sort of (response, index) keys in LDS, one 1024-thread workgroup per
+// frame.  The key order is KeypointGreater: the response decides (positive floats order like their bit patterns);
+// equal responses (rare) run the rest of the chain - size, octave, y, x - on the records.  The order is total, so the
+// network's result is the unique sorted sequence whatever order NMS appended in.
+constexpr int kBitonicMax = 16384;
+
+__device__ __forceinline__ bool kp_key_greater(unsigned long long a, unsigned long long b, const vo_keypoint* __restrict__ kps) {
+    const unsigned ra = (unsigned)(a >> 32), rb = (unsigned)(b >> 32);
+    if (ra != rb) return ra > rb;
+    const unsigned ia = (unsigned)a, ib = (unsigned)b;
+    if (ia == 0xffffffffu || ib == 0xffffffffu) return ib == 0xffffffffu && ia != 0xffffffffu;  // padding sorts last
+    const vo_keypoint p = kps[ia], q = kps[ib];
+    if (p.size != q.size) return p.size > q.size;
+    if (p.octave != q.octave) return p.octave > q.octave;
+    if (p.y != q.y) return p.y > q.y;
+    return p.x < q.x;
+}
+
+__global__ __launch_bounds__(1024) void k_sort_bitonic(const vo_keypoint* __restrict__ kp_base, int cap,
+                                                       const FrameCounters* __restrict__ cnt,
+                                                       vo_keypoint* __restrict__ out_base) {
+    extern __shared__ unsigned long long s_key[];
+    const int frame = blockIdx.x, tid = threadIdx.x;
+    const int n = min(cnt[frame].n_raw, cap);
+    if (n <= 0) return;
+    const vo_keypoint* kps = kp_base + (size_t)frame * cap;
+    int np = 1024;  // at least one compare-exchange per thread pair keeps the loops simple
+    while (np < n) np <<= 1;
+    for (int i = tid; i < np; i += 1024) {
+        unsigned long long key = 0xffffffffull;  // padding: lowest response, index -1
+        if (i < n) {
+            const unsigned bits = __float_as_uint(kps[i].response);
+            const unsigned mono = bits ^ ((bits >> 31) ? 0xffffffffu : 0x80000000u);  // float order -> unsigned order
+            key = ((unsigned long long)mono << 32) | (unsigned)i;
+        }
+        s_key[i] = key;
+    }
+    __syncthreads();
+    for (int k = 2; k <= np; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int t = tid; t < (np >> 1); t += 1024) {
+                const int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1)), hi = lo | j;
+                const bool desc = (lo & k) == 0;  // first half of every k-block sorted descending: the whole is descending
+                const unsigned long long a = s_key[lo], b = s_key[hi];
+                const bool a_gt_b = kp_key_greater(a, b, kps);
+                if (a_gt_b != desc) {
+                    s_key[lo] = b;
+                    s_key[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    vo_keypoint* out = out_base + (size_t)frame * cap;
+    for (int i = tid; i < n; i += 1024) out[i] = kps[(unsigned)s_key[i]];
+}
+
 // ------------------------------------------------------------------------------------------------
 // a5 + a6: orientation and descriptor, one wavefront (= one 64-thread workgroup) per keypoint.
 // ------------------------------------------------------------------------------------------------
@@ -1840,10 +1897,23 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
     {
         StageScope sc(ctx, ST_SORT);
         hipLaunchKernelGGL(k_count_clamp, dim3((fs.F + 255) / 256), dim3(256), 0, ctx->stream, fs.cnt, fs.cap, fs.F);
-        dim3 gr((fs.cap + 255) / 256, (fs.cap + kRankChunk - 1) / kRankChunk, fs.F);
-        hipLaunchKernelGGL(k_rank, gr, dim3(256), 0, ctx->stream, fs.kp_raw, fs.cap, fs.cnt, fs.rank);
-        hipLaunchKernelGGL(k_scatter, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp_raw, fs.cap,
-                           fs.cnt, fs.rank, fs.kp);
+        if (fs.cap <= kBitonicMax) {
+            int np = 1024;
+            while (np < fs.cap) np <<= 1;
+            const size_t lds = (size_t)np * sizeof(unsigned long long);
+            static bool attr_set = false;  // > 64 KB of dynamic LDS needs the attribute once per process
+            if (!attr_set) {
+                VO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_bitonic), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           kBitonicMax * (int)sizeof(unsigned long long)));
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(k_sort_bitonic, dim3(fs.F), dim3(1024), lds, ctx->stream, fs.kp_raw, fs.cap, fs.cnt, fs.kp);
+        } else {
+            dim3 gr((fs.cap + 255) / 256, (fs.cap + kRankChunk - 1) / kRankChunk, fs.F);
+            hipLaunchKernelGGL(k_rank, gr, dim3(256), 0, ctx->stream, fs.kp_raw, fs.cap, fs.cnt, fs.rank);
+            hipLaunchKernelGGL(k_scatter, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp_raw, fs.cap,
+                               fs.cnt, fs.rank, fs.kp);
+        }
         VO_HIP(hipGetLastError());
     }
     {
