@@ -229,6 +229,20 @@ __global__ __launch_bounds__(256) void k_colsum(const uint8_t* __restrict__ img,
     colsum[((size_t)frame * nbands + band) * W + x] = s;
 }
 
+// exclusive prefix of the band sums down every column (in place)
+__global__ __launch_bounds__(256) void k_colsum_scan(int W, int nbands, int32_t* __restrict__ colsum) {
+    const int frame = blockIdx.y;
+    const int x = blockIdx.x * 256 + threadIdx.x;
+    if (x >= W) return;
+    int32_t* p = colsum + (size_t)frame * nbands * W + x;
+    int32_t run = 0;
+    for (int b = 0; b < nbands; b++) {
+        const int32_t v = p[(size_t)b * W];
+        p[(size_t)b * W] = run;
+        run += v;
+    }
+}
+
 template <int CPT>
 __global__ __launch_bounds__(1024) void k_integral(const uint8_t* __restrict__ img, size_t img_stride, int H, int W,
                                                    int nbands, const int32_t* __restrict__ colsum,
@@ -241,15 +255,10 @@ __global__ __launch_bounds__(1024) void k_integral(const uint8_t* __restrict__ i
     int32_t* out = sum + (size_t)frame * sum_stride;
     const int32_t* cs = colsum + (size_t)frame * nbands * W;
     const int x0 = tid * CPT;
-    // column sums of all rows above this band
+    // column sums of all rows above this band (k_colsum_scan made them exclusive prefixes over the bands)
     int32_t carry[CPT];
 #pragma unroll
-    for (int c = 0; c < CPT; c++) carry[c] = 0;
-    for (int b = 0; b < band; b++) {
-#pragma unroll
-        for (int c = 0; c < CPT; c++)
-            if (x0 + c < W) carry[c] += cs[(size_t)b * W + x0 + c];
-    }
+    for (int c = 0; c < CPT; c++) carry[c] = (x0 + c < W) ? cs[(size_t)band * W + x0 + c] : 0;
     if (band == 0)
         for (int x = tid; x < sw; x += 1024) out[x] = 0;
     int32_t pre[kBand][CPT];  // inclusive prefix over the thread's columns, per row
@@ -293,6 +302,7 @@ int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs) {
     const int nbands = (fs.H + kBand - 1) / kBand;
     dim3 g1((fs.W + 255) / 256, nbands, fs.F);
     hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
+    hipLaunchKernelGGL(k_colsum_scan, dim3((fs.W + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.W, nbands, fs.colsum);
     dim3 g2(nbands, fs.F);
     const int cpt = (fs.W + 1023) / 1024;
 #define LAUNCH_INT(C)                                                                                              \
