@@ -37,12 +37,18 @@ int main() {
         vo::Mat33 K = {407.0646129842357, 0, 384.5, 0, 407.0646129842357, 246.5, 0, 0, 1}, R = {1, 0, 0, 0, 1, 0, 0, 0, 1};
         vo::Vec3 t = {0, 0, 0};
         bool ok = false;
-        if (!vo::Frontend::checkMinFeat(kP)) fe.optRelativePose(kP, K, R, t, inl, ok);
+        if (!vo::Frontend::checkMinFeat(kP) && vo::Frontend::checkIfMoving(kP)) fe.optRelativePose(kP, K, R, t, inl, ok);
         std::printf("inliers: %zu success: %d t = (%.3f %.3f %.3f)\n", inl.Kpoints1.size(), (int)ok, t[0], t[1], t[2]);
         if (ok) {
             int m = 0;
-            fe.triangPoints(inl.Kpoints1, inl.Kpoints2, R, t, K, &m);
+            const std::vector<double> wp = fe.triangPoints(inl.Kpoints1, inl.Kpoints2, R, t, K, &m);
             std::printf("world points: %d\n", m);
+            if (m > 0) {
+                const double SF = vo::Frontend::scaleFactor(7.5f, wp);
+                const vo::Mat33 I3 = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+                const auto ap = vo::Frontend::absolutePose(I3, vo::Vec3{0, 0, 0}, R, t, SF, &wp);
+                std::printf("scale factor %.3f, camera at (%.3f %.3f %.3f)\n", SF, ap.scaled_locW[0], ap.scaled_locW[1], ap.scaled_locW[2]);
+            }
         }
     } catch (const std::exception& e) {
         std::printf("error: %s\n", e.what());

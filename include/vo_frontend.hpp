@@ -102,7 +102,40 @@ class Frontend {
     }
 
     // checkMinFeat (:528): fewer than MIN_NUM_FEATURES matches -> FAIL_DETECTION
-    static bool checkMinFeat(const KpAsPoint2f_Match& kP) { return kP.Kpoints1.size() < 20; }
+    static bool checkMinFeat(const KpAsPoint2f_Match& kP) { return vo_check_min_feat((int)kP.Kpoints1.size(), 20.0) != 0; }
+
+    // checkIfMoving (:503): median match displacement >= DISTANCE (20 px); false -> NOT_MOVING
+    static bool checkIfMoving(const KpAsPoint2f_Match& kP) {
+        int moving = 0;
+        check(vo_check_if_moving(reinterpret_cast<const float*>(kP.Kpoints1.data()), reinterpret_cast<const float*>(kP.Kpoints2.data()),
+                                 (int)kP.Kpoints1.size(), 20.0, &moving, nullptr),
+              "vo_check_if_moving");
+        return moving != 0;
+    }
+
+    // scaleFactor (:384): world_points is the 3 x M row-major matrix triangPoints returned
+    static double scaleFactor(float distance, const std::vector<double>& world_points) {
+        double sf = 1.0;
+        check(vo_scale_factor(distance, world_points.data(), (int)(world_points.size() / 3), &sf), "vo_scale_factor");
+        return sf;
+    }
+
+    // absolutePose (:414, :467): returns scaled_locW, orient_wk and (when world_points is given) world_pointsW
+    struct AbsPose {
+        Vec3 scaled_locW;
+        Mat33 orient_wk;
+        std::vector<double> world_pointsW;
+    };
+    static AbsPose absolutePose(const Mat33& rotm, const Vec3& tran, const Mat33& orient, const Vec3& loc, double SF,
+                                const std::vector<double>* world_points = nullptr) {
+        AbsPose a;
+        const int n = world_points ? (int)(world_points->size() / 3) : 0;
+        a.world_pointsW.resize((size_t)3 * n);
+        check(vo_absolute_pose(rotm.data(), tran.data(), orient.data(), loc.data(), SF, world_points ? world_points->data() : nullptr,
+                               n, a.scaled_locW.data(), a.orient_wk.data(), n ? a.world_pointsW.data() : nullptr),
+              "vo_absolute_pose");
+        return a;
+    }
 
     vo_ctx* handle() { return ctx_; }
 

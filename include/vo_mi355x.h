@@ -208,6 +208,27 @@ int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes);
  * coordinates are not exactly representable); results are identical either way.                         */
 int vo_debug_set(vo_ctx* ctx, int key, int value);
 
+/* ---- N1: gates and pose chain of the node, host arithmetic only (no GPU, no context) ----------------
+ * These are the functions src/visual_Odometry.cpp calls around the three hot-path entry points, so that an offline
+ * replay can emit the reference's vo_results / fail_check fields.  Matrices row-major, 3-vectors plain.            */
+/* checkMinFeat, camera_utility.hpp:528 (MIN_NUM_FEATURES = 20.0, :12): 1 when the pair must be skipped           */
+int vo_check_min_feat(int n_matches, double min_features);
+/* checkIfMoving, camera_utility.hpp:503 (DISTANCE = 20.0 px, :11): float displacements, double median            */
+int vo_check_if_moving(const float* p1xy, const float* p2xy, int n, double distance, int* moving, double* median_px);
+/* scaleFactor, camera_utility.hpp:384: distance / mean(Z) of the 3 x n world points                              */
+int vo_scale_factor(float distance, const double* Xk, int n, double* sf);
+/* absolutePose (both overloads), camera_utility.hpp:414-501.  Xw may be NULL (the success = false overload)      */
+int vo_absolute_pose(const double rotm[9], const double tran[3], const double orient[9], const double loc[3], double sf,
+                     const double* Xk, int n, double t_wk[3], double R_wk[9], double* Xw);
+/* mat2Euler = tf::Matrix3x3::getRPY, math_utility.hpp:109                                                        */
+int vo_mat2euler(const double R[9], double rpy[3]);
+/* wrap2pi, math_utility.hpp:260; absDiff_Vec3 (three overloads), :265-310                                        */
+double vo_wrap2pi(double angle);
+int vo_abs_diff3(const double a[3], const double b[3], int is_angle, double out[3]);
+/* estimateTwist / computeAngularVel, math_utility.hpp:312-357                                                    */
+int vo_estimate_twist(double dt, const double R[9], const double t[3], double sf, const double rpy[3], const double Rbc[9],
+                      int motion2d, double lin[3], double ang[3]);
+
 /* Per-stage device timing (HIP events on the context's compute stream).  Enable, run,
  * sync, then read.  Stage names: vo_stage_name(i), i in [0, vo_stage_count()).           */
 int vo_profile_enable(vo_ctx* ctx, int on);

@@ -1,0 +1,111 @@
+"""CPU-only: the node's gates and pose chain against independent numpy restatements of the reference
+formulas (camera_utility.hpp:384-531, math_utility.hpp:109-357).  The reference has no fixtures for them and tf / OpenCV
+are absent: parity unpinned beyond these formulas."""
+import numpy as np
+import pytest
+
+from visual_odometry_amd import chain, synth
+
+
+def test_check_min_feat_threshold():
+    assert chain.checkMinFeat(19) and not chain.checkMinFeat(20) and chain.checkMinFeat(0)
+
+
+@pytest.mark.parametrize("n", [1, 2, 7, 20, 1001])
+def test_check_if_moving_is_float_displacement_double_median(n):
+    rng = np.random.default_rng(n)
+    p1 = rng.uniform(0, 600, (n, 2)).astype(np.float32)
+    p2 = (p1 + rng.normal(0, 18, (n, 2))).astype(np.float32)
+    d = p1 - p2
+    disp = np.sqrt((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32)).astype(np.float32).astype(np.float64)
+    s = np.sort(disp)
+    med = (s[n // 2 - 1] + s[n // 2]) / 2.0 if n % 2 == 0 else s[n // 2]
+    moving, got = chain.checkIfMoving(p1, p2, return_median=True)
+    assert got == med
+    assert moving == (med >= 20.0)
+
+
+def test_check_if_moving_boundary_and_gate():
+    p1 = np.zeros((30, 2), np.float32)
+    p2 = p1.copy()
+    p2[:, 0] = 20.0  # median exactly DISTANCE: "median < DISTANCE" is false -> moving
+    assert chain.checkIfMoving(p1, p2)
+    p2[:, 0] = 19.999
+    assert not chain.checkIfMoving(p1, p2)
+    assert chain.gate(p1, p2) == chain.NOT_MOVING
+    assert chain.gate(p1[:5], p2[:5]) == chain.FAIL_DETECTION
+    p2[:, 0] = 25
+    assert chain.gate(p1, p2) is None
+    with pytest.raises(ValueError):
+        chain.checkIfMoving(p1[:0], p2[:0])
+
+
+def test_scale_factor():
+    rng = np.random.default_rng(3)
+    X = rng.uniform(1, 9, (3, 500))
+    z = 0.0
+    for v in X[2]:
+        z += v
+    assert chain.scaleFactor(2.5, X) == np.float32(2.5) / (z / 500)
+    X[2] = 0
+    assert chain.scaleFactor(2.5, X) == 1.0
+
+
+def test_absolute_pose_both_overloads():
+    rng = np.random.default_rng(4)
+    rotm, orient = synth.rodrigues(rng.normal(0, 0.4, 3)), synth.rodrigues(rng.normal(0, 0.1, 3))
+    tran, loc, SF = rng.normal(0, 3, 3), rng.normal(0, 1, 3), 1.7
+    X = rng.uniform(-5, 5, (3, 40))
+    t_wk, R_wk, Xw = chain.absolutePose(rotm, tran, orient, loc, SF, X)
+    R_ref = rotm @ orient.T
+    t_ref = rotm @ (-SF * orient.T @ loc) + tran
+    np.testing.assert_allclose(R_wk, R_ref, rtol=0, atol=1e-14)
+    np.testing.assert_allclose(t_wk, t_ref, rtol=0, atol=1e-13)
+    np.testing.assert_allclose(Xw, R_ref @ (SF * X) + t_ref[:, None], rtol=0, atol=1e-12)
+    t2, R2 = chain.absolutePose(rotm, tran, orient, loc, SF)
+    assert np.array_equal(t2, t_wk) and np.array_equal(R2, R_wk)
+
+
+def _rpy_matrix(r, p, y):
+    cr, sr, cp, sp, cy, sy = np.cos(r), np.sin(r), np.cos(p), np.sin(p), np.cos(y), np.sin(y)
+    Rx = np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])
+    Ry = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]])
+    Rz = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]])
+    return Rz @ Ry @ Rx  # tf: R = Rz(yaw) Ry(pitch) Rx(roll)
+
+
+def test_mat2euler_inverts_tf_rpy_composition_and_gimbal_lock():
+    rng = np.random.default_rng(5)
+    for _ in range(50):
+        r, y = rng.uniform(-3, 3, 2)
+        p = rng.uniform(-1.5, 1.5)
+        np.testing.assert_allclose(chain.mat2Euler(_rpy_matrix(r, p, y)), [r, p, y], atol=1e-12)
+    # gimbal lock: R[2][0] = -1 -> pitch = +pi/2, yaw = 0, roll = atan2(R01, R02)
+    R = _rpy_matrix(0.3, np.pi / 2, 0.0)
+    R[2, 0] = -1.0
+    rpy = chain.mat2Euler(R)
+    assert rpy[2] == 0 and rpy[1] == np.pi / 2 and abs(rpy[0] - np.arctan2(R[0, 1], R[0, 2])) < 1e-15
+
+
+def test_wrap_and_abs_diff():
+    assert abs(chain.wrap2pi(3 * np.pi + 0.1) - (-np.pi + 0.1)) < 1e-12
+    np.testing.assert_allclose(chain.absDiff_Vec3([1, -2, 3], [0.5, 1, 5]), [0.5, 3, 2])
+    got = chain.absDiff_Vec3([3.1, -3.1, 0.2], [-3.1, 3.1, 0.1], True)
+    np.testing.assert_allclose(got, [2 * np.pi - 6.2, 2 * np.pi - 6.2, 0.1], atol=1e-12)
+
+
+def test_estimate_twist_2d_and_3d():
+    rng = np.random.default_rng(6)
+    R, Rbc = synth.rodrigues(rng.normal(0, 0.05, 3)), synth.rodrigues(rng.normal(0, 1, 3))
+    t, SF, dt = rng.normal(0, 1, 3), 2.2, 0.25
+    rpy = np.array([0.2, -0.3, 1.0])
+    lin, ang = chain.estimateTwist(dt, R, t, SF, rpy, Rbc, True)
+    np.testing.assert_allclose(lin, Rbc @ (-SF * R.T @ t / dt), atol=1e-13)
+    np.testing.assert_allclose(ang, [0, 0, np.arctan2(R[1, 0], R[0, 0]) / dt], atol=1e-15)
+    lin3, ang3 = chain.estimateTwist(dt, R, t, SF, rpy, Rbc, False)
+    d = chain.mat2Euler(R) / dt
+    w = [np.sin(rpy[0]) / np.cos(rpy[1]) * d[1] + np.cos(rpy[0]) / np.cos(rpy[1]) * d[2],
+         -d[0] - np.sin(rpy[0]) * np.tan(rpy[1]) * d[1] - np.cos(rpy[0]) * np.tan(rpy[1]) * d[2],
+         -np.cos(rpy[0]) * d[1] + np.sin(rpy[0]) * d[2]]
+    np.testing.assert_allclose(ang3, w, atol=1e-13)
+    assert np.array_equal(lin3, lin)
