@@ -200,6 +200,15 @@ int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out);
 int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask,
                         int cap, double* Xk, int cap_world);
 
+/* Sequence batch (offline replay of consecutive frames; no counterpart in the reference, which re-detects prev_img
+ * in every iteration, src/visual_Odometry.cpp:296): n_frames frames are detected and described once each;
+ * n_frames - 1 pairs, pair p = (frame p, frame p + 1) unless vo_seq_set_pair re-pairs it (the NOT_MOVING case keeps
+ * prev_img, :316-326).  vo_seq_set_pair must be called for every pair to give its K.  Run / sync / get / get_points /
+ * destroy are the vo_batch_* calls.                                                                              */
+int vo_seq_create(vo_ctx* ctx, int n_frames, int rows, int cols, vo_batch** out);
+int vo_seq_set_frame(vo_batch* b, int frame, const uint8_t* img, size_t step);
+int vo_seq_set_pair(vo_batch* b, int pair, int frame_a, int frame_b, const double K[9]);
+
 /* Inspection of the context's last single-call RANSAC (tests): what = 0 tuples [4096][5] int32,
  * 1 nmodels [4096] int32, 2 counts [4096][10] int32, 3 models [4096][10][9] double.              */
 int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes);

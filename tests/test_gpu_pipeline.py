@@ -74,3 +74,41 @@ def test_batch_1080p_pose_close_to_ground_truth_and_oracle():
     assert out1.status == 0 and out1.n_kp1 == out.n_kp2 and out1.n_kp2 == out.n_kp1
     b.close()
     c.close()
+
+
+def test_sequence_batch_shares_frame_features(ctx):
+    """vo_seq_*: three frames detected once each; pairs (0,1) and (1,2) give exactly what two independent pair-batch
+    entries give, and re-pairing (the NOT_MOVING case) works."""
+    from visual_odometry_amd.frontend import Batch, Sequence
+
+    sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 1001)
+    frames = [sc.img1, sc.img2, sc.img1]
+    seq = Sequence(ctx, 3, 480, 640)
+    for f, im in enumerate(frames):
+        seq.set_frame(f, im)
+    seq.set_pair(0, 0, 1, sc.K)
+    seq.set_pair(1, 1, 2, sc.K)
+    seq.run()
+    seq.sync()
+    ref = Batch(ctx, 2, 480, 640)
+    ref.set_pair(0, sc.img1, sc.img2, sc.K)
+    ref.set_pair(1, sc.img2, sc.img1, sc.K)
+    ref.run()
+    ref.sync()
+    for p in range(2):
+        a, b = seq.get(p), ref.get(p)
+        assert (a.status, a.n_kp1, a.n_kp2, a.n_match, a.n_inl, a.n_good, a.n_world, a.success, a.iters) == (
+            b.status, b.n_kp1, b.n_kp2, b.n_match, b.n_inl, b.n_good, b.n_world, b.success, b.iters)
+        assert list(a.E) == list(b.E) and list(a.R) == list(b.R) and list(a.t) == list(b.t)
+        pa, pb = seq.get_points(p), ref.get_points(p)
+        for x, y in zip(pa, pb):
+            assert np.array_equal(x, y)
+    assert seq.get(0).n_match > 50
+    # re-pair: frame 0 against frame 2 (identical images) -> every kept match has distance 0 and zero displacement
+    seq.set_pair(1, 0, 2, sc.K)
+    seq.run()
+    seq.sync()
+    p1, p2, m, _, _ = seq.get_points(1)
+    assert len(m) > 100 and np.array_equal(p1, p2) and np.all(m["distance"] == 0)
+    seq.close()
+    ref.close()

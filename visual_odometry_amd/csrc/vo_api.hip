@@ -357,10 +357,17 @@ int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp)
     VO_TRY(dalloc(ps.tmp, pm * 4));
     VO_TRY(dalloc(ps.st, (size_t)P));
     VO_HIP(hipMemset(ps.st, 0, (size_t)P * sizeof(PairState)));
+    VO_TRY(dalloc(ps.frames, (size_t)P));
+    {
+        std::vector<int2> f((size_t)P);
+        for (int p = 0; p < P; p++) f[p] = make_int2(2 * p, 2 * p + 1);
+        VO_HIP(hipMemcpy(ps.frames, f.data(), f.size() * sizeof(int2), hipMemcpyHostToDevice));
+    }
     return VO_OK;
 }
 
 void vo_pairset_free(PairSet& ps) {
+    dfree(ps.frames);
     dfree(ps.cand_val);
     dfree(ps.cand_idx);
     dfree(ps.knn_idx);
@@ -676,32 +683,83 @@ extern "C" int vo_triang_points(vo_ctx* ctx, const float* in1xy, const float* in
 }
 
 // ---------------------------------------------------------------- batch
-extern "C" int vo_batch_create(vo_ctx* ctx, int n_pairs, int rows, int cols, vo_batch** out) {
-    if (!ctx || !out || n_pairs <= 0) return VO_ERR_INVALID_ARG;
+static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq, int rows, int cols, vo_batch** out) {
+    if (!ctx || !out || n_pairs <= 0 || n_frames < 2) return VO_ERR_INVALID_ARG;
     *out = nullptr;
     if (rows < 16 || cols < 16 || rows > 8192 || cols > 8192) return VO_ERR_UNSUPPORTED;
     VO_HIP(hipSetDevice(ctx->device));
     vo_batch* b = new vo_batch();
     b->ctx = ctx;
     b->n_pairs = n_pairs;
+    b->n_frames = n_frames;
+    b->is_seq = is_seq;
     b->rows = rows;
     b->cols = cols;
-    int st = vo_frameset_alloc(b->fs, 2 * n_pairs, rows, cols, ctx->prm.kp_capacity);
+    int st = vo_frameset_alloc(b->fs, n_frames, rows, cols, ctx->prm.kp_capacity);
     if (st == VO_OK) st = vo_pairset_alloc(b->ps, n_pairs, ctx->prm.kp_capacity, round_up(ctx->prm.match_capacity, 64), kMaxHyp);
     if (st != VO_OK) {
         vo_batch_destroy(b);
         return st;
     }
-    if (hipHostMalloc((void**)&b->h_stage, (size_t)2 * n_pairs * rows * cols, hipHostMallocDefault) != hipSuccess ||
+    if (hipHostMalloc((void**)&b->h_stage, (size_t)n_frames * rows * cols, hipHostMallocDefault) != hipSuccess ||
         hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming) != hipSuccess) {
         vo_set_hip_error("hipHostMalloc/hipEventCreate", hipGetLastError(), __FILE__, __LINE__);
         vo_batch_destroy(b);
         return VO_ERR_HIP;
     }
     b->h_state.resize(n_pairs);
-    b->h_cnt.resize(2 * n_pairs);
+    b->h_cnt.resize(n_frames);
+    b->h_frames.resize(n_pairs);
+    for (int p = 0; p < n_pairs; p++) b->h_frames[p] = is_seq ? make_int2(p, p + 1) : make_int2(2 * p, 2 * p + 1);
+    b->frames_dirty = is_seq;  // vo_pairset_alloc wrote the (2p, 2p+1) default
     for (auto& S : b->h_state) init_state(S, 0, nullptr);
     *out = b;
+    return VO_OK;
+}
+
+extern "C" int vo_batch_create(vo_ctx* ctx, int n_pairs, int rows, int cols, vo_batch** out) {
+    return batch_create_impl(ctx, 2 * n_pairs, n_pairs, false, rows, cols, out);
+}
+
+// Sequence batch: n_frames frames, each detected and described ONCE, and n_frames - 1 pairs, pair p = (frame p, frame p + 1)
+// until vo_seq_set_pair re-pairs it.  The reference re-detects prev_img in every iteration (visual_Odometry.cpp:296);
+// for an offline replay the features of a frame serve both pairs it belongs to, which halves the detection work.
+extern "C" int vo_seq_create(vo_ctx* ctx, int n_frames, int rows, int cols, vo_batch** out) {
+    return batch_create_impl(ctx, n_frames, n_frames - 1, true, rows, cols, out);
+}
+
+static int stage_frame(vo_batch* b, int frame, const uint8_t* img, size_t step) {
+    // the caller's buffer may be pageable and may be reused as soon as this returns: the frame goes through the batch's
+    // pinned staging copy, the H2D transfer itself is asynchronous on the context's stream
+    if (b->upload_pending) {
+        VO_HIP(hipEventSynchronize(b->ev_upload));  // staging slots of the previous step are free again
+        b->upload_pending = false;
+    }
+    const size_t fbytes = (size_t)b->rows * b->cols;
+    uint8_t* dst = b->h_stage + (size_t)frame * fbytes;
+    if (step == (size_t)b->cols)
+        std::memcpy(dst, img, fbytes);
+    else
+        for (int r = 0; r < b->rows; r++) std::memcpy(dst + (size_t)r * b->cols, img + (size_t)r * step, b->cols);
+    VO_HIP(hipMemcpyAsync(b->fs.img + (size_t)frame * b->fs.img_stride(), dst, fbytes, hipMemcpyHostToDevice, b->ctx->stream));
+    b->state_dirty = true;
+    return VO_OK;
+}
+
+extern "C" int vo_seq_set_frame(vo_batch* b, int frame, const uint8_t* img, size_t step) {
+    if (!b || !b->is_seq || frame < 0 || frame >= b->n_frames) return VO_ERR_INVALID_ARG;
+    VO_TRY(check_image(img, b->rows, b->cols, step));
+    VO_HIP(hipSetDevice(b->ctx->device));
+    return stage_frame(b, frame, img, step);
+}
+
+extern "C" int vo_seq_set_pair(vo_batch* b, int pair, int frame_a, int frame_b, const double K[9]) {
+    if (!b || !b->is_seq || pair < 0 || pair >= b->n_pairs || !K) return VO_ERR_INVALID_ARG;
+    if (frame_a < 0 || frame_a >= b->n_frames || frame_b < 0 || frame_b >= b->n_frames) return VO_ERR_INVALID_ARG;
+    b->h_frames[pair] = make_int2(frame_a, frame_b);
+    b->frames_dirty = true;
+    init_state(b->h_state[pair], 0, K);
+    b->state_dirty = true;
     return VO_OK;
 }
 
@@ -718,28 +776,12 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
 
 extern "C" int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, size_t step1, const uint8_t* img2, size_t step2,
                                  const double K[9]) {
-    if (!b || pair < 0 || pair >= b->n_pairs || !K) return VO_ERR_INVALID_ARG;
+    if (!b || b->is_seq || pair < 0 || pair >= b->n_pairs || !K) return VO_ERR_INVALID_ARG;
     VO_TRY(check_image(img1, b->rows, b->cols, step1));
     VO_TRY(check_image(img2, b->rows, b->cols, step2));
     VO_HIP(hipSetDevice(b->ctx->device));
-    // the caller's buffers may be pageable and may be reused as soon as this returns: the frames go through the batch's
-    // pinned staging copy, the H2D transfer itself is asynchronous on the context's stream
-    if (b->upload_pending) {
-        VO_HIP(hipEventSynchronize(b->ev_upload));  // staging slots of the previous step are free again
-        b->upload_pending = false;
-    }
-    const size_t fbytes = (size_t)b->rows * b->cols;
-    const uint8_t* src[2] = {img1, img2};
-    const size_t steps[2] = {step1, step2};
-    for (int v = 0; v < 2; v++) {
-        uint8_t* dst = b->h_stage + (size_t)(2 * pair + v) * fbytes;
-        if (steps[v] == (size_t)b->cols)
-            std::memcpy(dst, src[v], fbytes);
-        else
-            for (int r = 0; r < b->rows; r++) std::memcpy(dst + (size_t)r * b->cols, src[v] + (size_t)r * steps[v], b->cols);
-        VO_HIP(hipMemcpyAsync(b->fs.img + (size_t)(2 * pair + v) * b->fs.img_stride(), dst, fbytes, hipMemcpyHostToDevice,
-                              b->ctx->stream));
-    }
+    VO_TRY(stage_frame(b, 2 * pair, img1, step1));
+    VO_TRY(stage_frame(b, 2 * pair + 1, img2, step2));
     init_state(b->h_state[pair], 0, K);
     b->state_dirty = true;
     return VO_OK;
@@ -754,6 +796,11 @@ extern "C" int vo_batch_run(vo_batch* b) {
         b->upload_pending = true;
     }
     VO_TRY(reset_counters(ctx, b->fs));
+    if (b->frames_dirty) {
+        VO_HIP(hipMemcpyAsync(b->ps.frames, b->h_frames.data(), b->h_frames.size() * sizeof(int2), hipMemcpyHostToDevice,
+                              ctx->stream));
+        b->frames_dirty = false;
+    }
     if (b->state_dirty) {
         // K / initial pose of every pair; the kernels reset everything else themselves
         b->h_init = b->h_state;
@@ -796,8 +843,8 @@ extern "C" int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out) {
     VO_TRY(batch_fetch(b));
     const PairState& S = b->h_state[pair];
     std::memset(out, 0, sizeof(*out));
-    out->n_kp1 = b->h_cnt[2 * pair].n_raw;
-    out->n_kp2 = b->h_cnt[2 * pair + 1].n_raw;
+    out->n_kp1 = b->h_cnt[b->h_frames[pair].x].n_raw;
+    out->n_kp2 = b->h_cnt[b->h_frames[pair].y].n_raw;
     out->n_match = S.n_match;
     out->status = S.status;
     if (out->n_kp1 > b->fs.cap || out->n_kp2 > b->fs.cap || S.n_match > b->ps.match_cap) out->status = VO_ERR_CAPACITY;

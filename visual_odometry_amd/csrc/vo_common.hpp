@@ -144,6 +144,7 @@ struct FrameSet {
 struct PairSet {
     int P = 0, kp_cap = 0, match_cap = 0, max_hyp = 0;
     int n_split = 0;            // train-range splits of the MFMA pass
+    int2* frames = nullptr;     // [P] (query frame, train frame) of every pair; default (2p, 2p+1)
     float* cand_val = nullptr;  // [P][kp_cap][n_split*4]
     int* cand_idx = nullptr;
     int* knn_idx = nullptr;     // [P][kp_cap][2]
@@ -192,6 +193,10 @@ struct vo_batch {
     std::vector<PairState> h_state, h_init;  // host mirrors (results / initial K and pose)
     std::vector<FrameCounters> h_cnt;
     bool state_dirty = true, fetched = false;
+    int n_frames = 0;                // frames held (2 * n_pairs for a pair batch, n_pairs + 1 for a sequence)
+    bool is_seq = false;
+    std::vector<int2> h_frames;      // host copy of ps.frames
+    bool frames_dirty = false;
     uint8_t* h_stage = nullptr;      // pinned staging copy of the frames: vo_batch_set_pair returns before the H2D copy ends
     hipEvent_t ev_upload = nullptr;  // recorded after the latest frame upload
     bool upload_pending = false;

@@ -58,9 +58,10 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ de
                                                     const float4* __restrict__ descT_base,
                                                     const float* __restrict__ nrm_base,
                                                     const FrameCounters* __restrict__ cnt, int cap,
+                                                    const int2* __restrict__ pair_frames,
                                                     float* __restrict__ cand_val, int* __restrict__ cand_idx) {
     const int pair = blockIdx.y;
-    const int fa = 2 * pair, fb = 2 * pair + 1;
+    const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
     const int nA = min(cnt[fa].n_raw, cap), nB = min(cnt[fb].n_raw, cap);
     const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
     const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -155,10 +156,11 @@ __device__ __forceinline__ void min_pair32(float& d, int& i) {
 
 __global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ desc_base,
                                                       const FrameCounters* __restrict__ cnt, int cap,
+                                                      const int2* __restrict__ pair_frames,
                                                       const int* __restrict__ cand_idx, int* __restrict__ knn_idx,
                                                       float* __restrict__ knn_dist) {
     const int pair = blockIdx.y;
-    const int fa = 2 * pair, fb = 2 * pair + 1;
+    const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
     const int nA = min(cnt[fa].n_raw, cap), nB = min(cnt[fb].n_raw, cap);
     const int q = blockIdx.x * 8 + (threadIdx.x >> 5), sub = threadIdx.x & 31;
     if (q >= nA) return;
@@ -196,6 +198,7 @@ __global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_match_filter(const vo_keypoint* __restrict__ kp_base,
                                                        const FrameCounters* __restrict__ cnt, int cap,
+                                                       const int2* __restrict__ pair_frames,
                                                        const int* __restrict__ knn_idx, const float* __restrict__ knn_dist,
                                                        float ratio, float x_lo, float y_lo, float x_hi, float y_hi,
                                                        int match_cap, float* __restrict__ p1, float* __restrict__ p2,
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(1024) void k_match_filter(const vo_keypoint* __rest
     __shared__ int s_wtot[16];
     __shared__ int s_base;
     const int pair = blockIdx.x;
-    const int fa = 2 * pair, fb = 2 * pair + 1;
+    const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
     const int nA = min(cnt[fa].n_raw, cap);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const vo_keypoint* kA = kp_base + (size_t)fa * cap;
@@ -276,17 +279,17 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
         StageScope sc(ctx, ST_MATCH_MFMA);
         const int waves = (cap / 64) * kSplit;
         hipLaunchKernelGGL(k_match_mfma, dim3(waves / 4, P), dim3(256), 0, ctx->stream, fs.desc,
-                           reinterpret_cast<const float4*>(fs.descT), fs.nrm, fs.cnt, cap, ps.cand_val, ps.cand_idx);
+                           reinterpret_cast<const float4*>(fs.descT), fs.nrm, fs.cnt, cap, ps.frames, ps.cand_val, ps.cand_idx);
         VO_HIP(hipGetLastError());
     }
     {
         StageScope sc(ctx, ST_MATCH_SELECT);
-        hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.cand_idx,
-                           ps.knn_idx, ps.knn_dist);
+        hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames,
+                           ps.cand_idx, ps.knn_idx, ps.knn_dist);
         if (filter) {
             const vo_params& p = ctx->prm;
-            hipLaunchKernelGGL(k_match_filter, dim3(P), dim3(1024), 0, ctx->stream, fs.kp, fs.cnt, cap, ps.knn_idx,
-                               ps.knn_dist, p.ratio_thresh, p.roi_x_lo, p.roi_y_lo, p.roi_x_hi, p.roi_y_hi, ps.match_cap,
+            hipLaunchKernelGGL(k_match_filter, dim3(P), dim3(1024), 0, ctx->stream, fs.kp, fs.cnt, cap, ps.frames,
+                               ps.knn_idx, ps.knn_dist, p.ratio_thresh, p.roi_x_lo, p.roi_y_lo, p.roi_x_hi, p.roi_y_hi, ps.match_cap,
                                ps.p1, ps.p2, ps.matches, ps.st);
         }
         VO_HIP(hipGetLastError());

@@ -262,10 +262,11 @@ class Context:
 class Batch:
     """Device-resident batch of frame pairs (vo_batch_*)."""
 
-    def __init__(self, ctx: Context, n_pairs: int, rows: int, cols: int):
+    def __init__(self, ctx: Context, n_pairs: int, rows: int, cols: int, _create=True):
         self.ctx, self.n_pairs, self.rows, self.cols = ctx, n_pairs, rows, cols
         self._h = C.c_void_p()
-        ctx._chk(ctx.lib.vo_batch_create(ctx._h, n_pairs, rows, cols, C.byref(self._h)))
+        if _create:
+            ctx._chk(ctx.lib.vo_batch_create(ctx._h, n_pairs, rows, cols, C.byref(self._h)))
 
     def close(self):
         if self._h:
@@ -308,3 +309,21 @@ class Batch:
         o = self.get(i)
         nm = max(o.n_match, 0)
         return p1[:nm], p2[:nm], m[:nm], mask[:nm], X[:, : max(o.n_world, 0)]
+
+
+class Sequence(Batch):
+    """Device-resident run of consecutive frames (vo_seq_*): every frame is detected and described once, pair p is
+    (frame p, frame p + 1) unless set_pair re-pairs it.  run / sync / get / get_points as for Batch."""
+
+    def __init__(self, ctx: Context, n_frames: int, rows: int, cols: int):
+        super().__init__(ctx, n_frames - 1, rows, cols, _create=False)
+        self.n_frames = n_frames
+        ctx._chk(ctx.lib.vo_seq_create(ctx._h, n_frames, rows, cols, C.byref(self._h)))
+
+    def set_frame(self, f, img):
+        img = _img(img)
+        self.ctx._chk(self.ctx.lib.vo_seq_set_frame(self._h, f, _p(img, u8p), C.c_size_t(img.strides[0])))
+
+    def set_pair(self, i, frame_a, frame_b, K):  # noqa: D102  (different signature from Batch.set_pair on purpose)
+        K = np.ascontiguousarray(K, np.float64)
+        self.ctx._chk(self.ctx.lib.vo_seq_set_pair(self._h, i, int(frame_a), int(frame_b), _p(K, f64p)))
