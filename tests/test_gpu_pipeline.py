@@ -112,3 +112,45 @@ def test_sequence_batch_shares_frame_features(ctx):
     assert len(m) > 100 and np.array_equal(p1, p2) and np.all(m["distance"] == 0)
     seq.close()
     ref.close()
+
+
+def test_replay_follows_the_node_loop(ctx):
+    """C3-style sequence through visual_odometry_amd.replay: gate sequence, prev_img bookkeeping across NOT_MOVING and
+    FAIL_DETECTION frames, pose carry-over, scale factor and the pose chain (src/visual_Odometry.cpp:268-470)."""
+    from visual_odometry_amd import chain, replay
+
+    step = 0.45
+    poses = [((0, 0, 0), (0, 0, 0)), ((0.5, -0.3, 1.0), (step, 0.02, 0.0)), ((1.0, 0.2, 2.0), (2 * step, 0.05, 0.02))]
+    poses += [poses[2], poses[2]]  # frames 3, 4: the camera stands still
+    poses += [((0.8, 0.5, 3.0), (3 * step, 0.0, 0.03)), ((0, 0, 0), (4 * step, 0, 0)), ((0.3, 0.2, 3.5), (5 * step, 0.03, 0.0)),
+              ((0.1, 0.6, 4.0), (6 * step, 0.06, 0.01))]
+    sc = synth.sequence_scene(480, 640, synth.K_PARETE, 900, 3003, poses, blank=(6,))
+    n = len(sc.frames)
+    stamps = np.arange(n) * 0.5
+    alt = np.full(n, 7.0)
+    recs = replay.replay(ctx, sc.frames, stamps, alt, sc.K, np.eye(3), np.zeros(3), chunk=4)
+    assert [r["frame"] for r in recs] == list(range(1, n))
+    fails = [r["fail"] for r in recs]
+    S, NM, FD = chain.SUCCESS, chain.NOT_MOVING, chain.FAIL_DETECTION
+    assert fails == [S, S, NM, NM, S, FD, FD, S], fails
+    assert [r["prev"] for r in recs] == [0, 1, 2, 2, 2, 5, 6, 7]
+    for r in recs:
+        if r["fail"] != S:
+            assert "R" not in r
+            continue
+        Rgt, tgt, base = sc.relative(r["prev"], r["frame"])
+        assert _angle(r["R"], Rgt) < 0.5, (r["frame"], _angle(r["R"], Rgt))
+        assert np.degrees(np.arccos(np.clip(r["t"] @ tgt, -1, 1))) < 10.0  # ~150 matches, 2 px RANSAC threshold
+        assert r["world_pointsW"].shape[0] == 3 and r["world_pointsW"].shape[1] > 20
+        # scaleFactor = altitude / mean depth in |t| = 1 units; the scene is 5-9 m deep and the altitude 7 m, so SF must
+        # come out near the true baseline
+        assert 0.5 * base < r["SF"] < 2.0 * base, (r["SF"], base)
+    # the chain: position advances along +x of the start frame by roughly SF * |t| per successful step, and the
+    # absolute orientation is the product of the relative ones
+    last = recs[-1]
+    Rtot = np.eye(3)
+    for r in recs:
+        if r["fail"] == S:
+            Rtot = Rtot @ r["R"].T
+    np.testing.assert_allclose(last["orientation"], Rtot, atol=1e-12)
+    assert last["estimate_pos"][0] > 1.0

@@ -12,7 +12,7 @@ from . import _abi
 DISTANCE = 20.0  # camera_utility.hpp:11
 MIN_NUM_FEATURES = 20.0  # camera_utility.hpp:12
 # enum fail_V0 (visual_Odometry.cpp:58)
-FAIL_DETECTION, NOT_MOVING, FAIL_ESSENTIAL = 0, 1, 2
+FAIL_DETECTION, NOT_MOVING, FAIL_RECOVER, SUCCESS = 0, 1, 2, 3
 
 _lib = None
 _f32p, _f64p = C.POINTER(C.c_float), C.POINTER(C.c_double)

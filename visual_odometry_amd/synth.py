@@ -172,3 +172,59 @@ def scene_c2(seed: int = 2002) -> Scene:
 def roi_for(h: int, w: int, border: float = 0.04):
     """ROI of the reference scaled to the frame: the image minus a 4 % border."""
     return (round(border * w), round(border * h), round((1 - border) * w), round((1 - border) * h))
+
+
+@dataclasses.dataclass
+class SequenceScene:
+    frames: list  # uint8 [H, W] each
+    K: np.ndarray
+    Rw: list  # X_k = Rw[k] @ X_0 + tw[k]
+    tw: list
+
+    def relative(self, j: int, k: int):
+        """(R, t_unit, |t|) with X_k = R X_j + t, the convention of recoverPose."""
+        R = self.Rw[k] @ self.Rw[j].T
+        t = self.tw[k] - R @ self.tw[j]
+        n = float(np.linalg.norm(t))
+        return R, (t / n if n > 0 else t), n
+
+
+def sequence_scene(h: int, w: int, K: np.ndarray, n_blobs: int, seed: int, poses, depth=(5.0, 9.0), sigma_px=(1.6, 6.0),
+                   noise_amp: float = 2.0, blank=()) -> SequenceScene:
+    """C3-style run: one static blob world seen from `poses` = [(rotvec_deg[3], position[3]) ...] (camera k sits at
+    position c_k in the frame of camera 0 with orientation rodrigues(rotvec)); frames listed in `blank` are rendered
+    without any structure (FAIL_DETECTION).  Repeating a pose gives a stationary frame (NOT_MOVING) with fresh noise."""
+    rng = np.random.default_rng(seed)
+    m = 0.35  # the world extends beyond view 0 so that later views stay covered
+    u = rng.uniform(-m * w, (1 + m) * w, size=n_blobs)
+    v = rng.uniform(-m * h, (1 + m) * h, size=n_blobs)
+    z = rng.uniform(depth[0], depth[1], size=n_blobs)
+    s1 = np.exp(rng.uniform(np.log(sigma_px[0]), np.log(sigma_px[1]), size=n_blobs))
+    amp = rng.uniform(30.0, 90.0, size=n_blobs) * rng.choice([-1.0, 1.0], size=n_blobs)
+    ns = 3
+    phi = rng.uniform(0, 2 * np.pi, size=(ns, n_blobs))
+    rad = rng.uniform(1.2, 2.8, size=(ns, n_blobs)) * s1
+    sfac = rng.uniform(0.5, 0.9, size=(ns, n_blobs))
+    afac = rng.uniform(0.35, 0.9, size=(ns, n_blobs)) * rng.choice([-1.0, 1.0], size=(ns, n_blobs))
+    du = np.concatenate([np.zeros(n_blobs)] + [rad[k] * np.cos(phi[k]) for k in range(ns)])
+    dv = np.concatenate([np.zeros(n_blobs)] + [rad[k] * np.sin(phi[k]) for k in range(ns)])
+    ua, va, za = np.tile(u, ns + 1) + du, np.tile(v, ns + 1) + dv, np.tile(z, ns + 1)
+    sa = np.concatenate([s1] + [sfac[k] * s1 for k in range(ns)])
+    aa = np.concatenate([amp] + [afac[k] * amp for k in range(ns)])
+    X0 = (np.linalg.inv(K) @ np.stack([ua, va, np.ones_like(ua)])) * za
+    frames, Rw, tw = [], [], []
+    for k, (rv, c) in enumerate(poses):
+        Rk = rodrigues(np.deg2rad(np.asarray(rv, np.float64))).T  # world (camera 0) -> camera k
+        tk = -Rk @ np.asarray(c, np.float64)
+        Xk = Rk @ X0 + tk[:, None]
+        noise = _value_noise(rng, h, w, 6, noise_amp)
+        if k in blank:
+            img = np.clip(np.rint(128.0 + noise), 0, 255).astype(np.uint8)
+        else:
+            ok = Xk[2] > 0.5
+            uv = ((K @ Xk)[:2] / Xk[2]).T
+            img = _render(h, w, uv[ok], (sa * za / Xk[2])[ok], aa[ok], noise)
+        frames.append(img)
+        Rw.append(Rk)
+        tw.append(tk)
+    return SequenceScene(frames, K.copy(), Rw, tw)
