@@ -1469,7 +1469,9 @@ __device__ __forceinline__ int bilinear_u8(uint32_t q, float a, float b) {
     float v = r0.x + r0.y;
     v = v + r1.x;
     v = v + r1.y;
-    return (int)(uint8_t)d_cvRoundF(v);
+    // v_cvt_pk_u8_f32: round to nearest even + saturate to u8 in one instruction (v is in [0, 255], so the
+    // saturation never acts and this is cvRound followed by the uchar cast)
+    return (int)__builtin_amdgcn_cvt_pk_u8_f32(v, 0u, 0u);
 }
 
 // U samples of one lane at columns j0 + u * CB, all inside the window.  (px0, py0) is the exact position of
