@@ -960,18 +960,26 @@ __device__ __forceinline__ void describe_orientation(const int32_t* __restrict__
         // angular distance serves both: |A - i0| < 30 or > 330 is window L, 150 < |A - i0| < 210 is window L + 36.
         // Samples outside a window add +0.f, which leaves a float sum bit-identical to skipping them.
         const int i0 = (lane < 36 ? lane : 0) * 5, i1 = i0 + 180;
-        float sx0 = 0, sy0 = 0, sx1 = 0, sy1 = 0;
+        typedef float f32x2_t __attribute__((ext_vector_type(2)));
+        f32x2_t acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
 #pragma unroll 4
         for (int j = 0; j < nangle; j++) {
             const int A = s_A[j];
-            const float X = s_X[j], Y = s_Y[j];
+            const f32x2_t xy = {s_X[j], s_Y[j]};
             const unsigned d0 = (unsigned)abs(A - i0);
-            const bool in0 = d0 - 30u > 300u, in1 = d0 - 151u < 59u;
-            sx0 += in0 ? X : 0.f;
-            sy0 += in0 ? Y : 0.f;
-            sx1 += in1 ? X : 0.f;
-            sy1 += in1 ? Y : 0.f;
+            // lanes whose window holds the sample add it under EXEC (one packed add per window; skipping a lane is the
+            // same as adding +0.f): the kernel is bound by VALU issue, and selects would cost two more instructions each;
+            // the empty asm keeps each add a real branch under EXEC instead of two selects + add
+            if (d0 - 30u > 300u) {
+                acc0 += xy;
+                asm volatile("" : "+v"(acc0));
+            }
+            if (d0 - 151u < 59u) {
+                acc1 += xy;
+                asm volatile("" : "+v"(acc1));
+            }
         }
+        const float sx0 = acc0.x, sy0 = acc0.y, sx1 = acc1.x, sy1 = acc1.y;
         const float m0 = sx0 * sx0 + sy0 * sy0;
         if (lane < 36 && m0 > best_mod) {
             best_mod = m0;
