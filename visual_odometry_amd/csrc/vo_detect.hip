@@ -839,10 +839,6 @@ __device__ __forceinline__ int sample_pixel(const uint8_t* __restrict__ img, int
     return img[(size_t)y * W + x];
 }
 
-// pitch of 25 dwords: odd, so lanes that walk down image rows fall into different LDS banks
-constexpr bool kStageTiles = false;  // false: bilinear taps gathered straight from L1/L2 (measured faster)
-constexpr int kTileCols = 32, kTileWidth = 96, kTilePitch = 100, kTileRows = 80;
-
 __device__ __forceinline__ void wave_sync_lds() {  // LDS hand-off between lanes of one wavefront
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
@@ -850,44 +846,6 @@ __device__ __forceinline__ void wave_sync_lds() {  // LDS hand-off between lanes
 }
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
-
-__device__ __noinline__ uint32_t global_taps(const uint8_t* __restrict__ img, int W, int ix, int iy) {
-    const uint8_t* p = img + (size_t)iy * W + ix;
-    return (uint32_t)p[0] | ((uint32_t)p[1] << 8) | ((uint32_t)p[W] << 16) | ((uint32_t)p[W + 1] << 24);
-}
-
-// sample_pixel with the 2x2 footprint taken from the staged LDS tile [y0..y1] x [x0..x1] when it lies inside
-__device__ __forceinline__ int sample_pixel_tile(const uint8_t* __restrict__ img, int W, int ncols1, int nrows1, double px,
-                                                 double py, const uint8_t* tile, bool use_lds, int x0, int y0, int x1, int y1) {
-    const int ix = d_cvFloorD(px), iy = d_cvFloorD(py);
-    if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
-        const float a = (float)(px - ix), b = (float)(py - iy);
-        int p00, p01, p10, p11;
-        if (__builtin_expect(use_lds && ix >= x0 && ix + 1 <= x1 && iy >= y0 && iy + 1 <= y1, 1)) {
-            // explicit LDS address space: keeps these ds_read_u8 instead of flat loads through a merged pointer
-            const lds_u8* p = (const lds_u8*)tile + (iy - y0) * kTilePitch + (ix - x0);
-            p00 = p[0];
-            p01 = p[1];
-            p10 = p[kTilePitch];
-            p11 = p[kTilePitch + 1];
-        } else {
-            const uint32_t t = global_taps(img, W, ix, iy);
-            p00 = t & 255;
-            p01 = (t >> 8) & 255;
-            p10 = (t >> 16) & 255;
-            p11 = t >> 24;
-        }
-        const float oma = 1.f - a, omb = 1.f - b;
-        float v = (float)p00 * oma * omb;
-        v = v + (float)p01 * a * omb;
-        v = v + (float)p10 * oma * b;
-        v = v + (float)p11 * a * b;
-        return (int)(uint8_t)d_cvRoundF(v);
-    }
-    const int x = min(max(d_cvRoundD(px), 0), ncols1);
-    const int y = min(max(d_cvRoundD(py), 0), nrows1);
-    return img[(size_t)y * W + x];
-}
 
 __device__ __forceinline__ int saturate_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
@@ -1122,7 +1080,8 @@ __device__ __forceinline__ void describe_patch_to_vec(int tid, int NT, const uin
     }
 }
 
-// WLO < win <= WHI selects the instance; NT threads cooperate on one keypoint (64 = one wavefront).
+// The reference's own walk, kept as the fallback for keypoints whose window coordinates are not exact in closed form
+// (see k_describe_tiled): correctness over speed.  NT threads cooperate on one keypoint of list `cls`.
 template <int WLO, int WHI, int NT>
 __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                  const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
@@ -1137,7 +1096,6 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     __shared__ float s_vec[64];
     __shared__ float s_dir;
     __shared__ int s_item;
-    __shared__ __attribute__((aligned(16))) uint8_t s_tile[kStageTiles ? (NT / 64) * kTilePitch * kTileRows : 16];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -1184,8 +1142,8 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     const int ncols1 = W - 1, nrows1 = H - 1;
 
     // rows of the window: thread <-> row, columns walked sequentially so that the double coordinate
-    // accumulation (pixel_x += cos_dir) is reproduced step for step; the row never exists as pixels,
-    // it is folded straight into the 21 horizontal accumulators of the INTER_AREA row pass.
+    // accumulation (pixel_x += cos_dir) is reproduced step for step, whatever the values; the row never exists as
+    // pixels, it is folded straight into the 21 horizontal accumulators of the INTER_AREA row pass.
 #pragma unroll 1
     for (int r = 0; r < tid; r++) {
         start_x += sin_dir;
@@ -1193,176 +1151,32 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     }
     int* s_rowint = reinterpret_cast<int*>(s_rowbuf);
     const double dcos = (double)cos_dir, dsin = (double)sin_dir;
-    // The window is walked in tiles of 64 rows (one per lane) x kTileCols columns.  The image footprint of
-    // a tile (<= 76 x 79 px for any rotation) is staged into LDS with coalesced dword loads, so the four
-    // bilinear taps of every sample are LDS byte reads instead of scattered global byte loads.
-    uint8_t* tile = s_tile + (kStageTiles ? (tid >> 6) * (kTilePitch * kTileRows) : 0);
-    const bool w16 = (W & 15) == 0;  // rows of the frame are 16-byte aligned
     for (int base = 0; base < win; base += NT) {
         const int i = base + tid;
-        const bool active = i < win;
-        double px = (double)start_x, py = (double)start_y;
-        float facc = 0.f;
-        int iacc = 0, c = 0, left = iscale;
-        if (base + (tid & ~63) < win) {  // wavefront has at least one row
-            for (int j0 = 0; j0 < win; j0 += kTileCols) {
-                const int tj = min(kTileCols, win - j0);
-                int lx = 0x7fffffff, hx = -0x7fffffff, ly = 0x7fffffff, hy = -0x7fffffff;
-                if (kStageTiles && active) {
-                    const double xb = px + (tj - 1) * dcos, yb = py - (tj - 1) * dsin;
-                    lx = d_cvFloorD(fmin(px, xb)) - 1;  // one pixel of slack: the walk below accumulates step by step
-                    hx = d_cvFloorD(fmax(px, xb)) + 2;
-                    ly = d_cvFloorD(fmin(py, yb)) - 1;
-                    hy = d_cvFloorD(fmax(py, yb)) + 2;
-                }
-#pragma unroll
-                for (int d = kStageTiles ? 32 : 0; d >= 1; d >>= 1) {
-                    lx = min(lx, __shfl_xor(lx, d, 64));
-                    hx = max(hx, __shfl_xor(hx, d, 64));
-                    ly = min(ly, __shfl_xor(ly, d, 64));
-                    hy = max(hy, __shfl_xor(hy, d, 64));
-                }
-                const int x0 = max(lx, 0) & ~15, x1 = min(hx, W - 1), y0 = max(ly, 0), y1 = min(hy, H - 1);
-                const int tw = x1 - x0 + 1, th = y1 - y0 + 1;
-                const bool use_lds = kStageTiles && tw > 0 && th > 0 && tw <= kTileWidth && th <= kTileRows;
-                if (kStageTiles) wave_sync_lds();  // previous tile fully consumed
-                if (use_lds) {
-                    if (w16) {
-                        // 8 lanes x 16 B cover one tile row, 8 rows per wave instruction
-                        const int q = lane & 7;
-                        if (16 * q < tw) {
-                            for (int r = lane >> 3; r < th; r += 8) {
-                                const uint4 v = *reinterpret_cast<const uint4*>(img + (size_t)(y0 + r) * W + x0 + 16 * q);
-                                uint32_t* dst = reinterpret_cast<uint32_t*>(tile + r * kTilePitch + 16 * q);
-                                dst[0] = v.x;
-                                dst[1] = v.y;
-                                dst[2] = v.z;
-                                dst[3] = v.w;
-                            }
-                        }
-                    } else {
-                        for (int r = 0; r < th; r++)
-                            for (int d = lane; d < tw; d += 64) tile[r * kTilePitch + d] = img[(size_t)(y0 + r) * W + x0 + d];
+        if (i < win) {
+            double px = (double)start_x, py = (double)start_y;
+            float facc = 0.f;
+            int iacc = 0, c = 0, left = iscale;
+            for (int j = 0; j < win; j++) {
+                const int Sv = sample_pixel(img, W, ncols1, nrows1, px, py);
+                px += dcos;
+                py -= dsin;
+                if (area_fast) {
+                    iacc += Sv;
+                    if (--left == 0) {
+                        s_rowint[i * (kPatch + 1) + c] = iacc;
+                        c++;
+                        iacc = 0;
+                        left = iscale;
                     }
-                }
-                if (kStageTiles) wave_sync_lds();
-                {
-                    // Samples are taken 8 at a time: coordinates first (the sequential double accumulation),
-                    // then 32 LDS byte reads in flight together, then the arithmetic.  The batch takes the
-                    // straight-line path when every sample of every active lane has its 2x2 footprint
-                    // inside the staged tile and the image interior (always, except at the frame border).
-                    int jj = 0;
-                    for (; jj + 8 <= tj; jj += 8) {
-                        double qx[8], qy[8];
-                        int ax[8], ay[8];
-                        bool ok = true;
-#pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            qx[u] = px;
-                            qy[u] = py;
-                            px += dcos;
-                            py -= dsin;
-                            const int ix = d_cvFloorD(qx[u]), iy = d_cvFloorD(qy[u]);
-                            ok = ok && (unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1;
-                            if (kStageTiles) ok = ok && use_lds && ix >= x0 && ix + 1 <= x1 && iy >= y0 && iy + 1 <= y1;
-                            ax[u] = ix;
-                            ay[u] = iy;
-                        }
-                        int S[8];
-                        if (__ballot(active && !ok) == 0ull) {
-                            int p00[8], p01[8], p10[8], p11[8];
-                            if (kStageTiles) {
-                                const lds_u8* tp = (const lds_u8*)tile;
-#pragma unroll
-                                for (int u = 0; u < 8; u++) {
-                                    // clamped so that idle lanes read inside the tile too
-                                    const int ry = min(max(ay[u] - y0, 0), kTileRows - 2), rx = min(max(ax[u] - x0, 0), kTileWidth - 2);
-                                    const lds_u8* p = tp + ry * kTilePitch + rx;
-                                    p00[u] = p[0];
-                                    p01[u] = p[1];
-                                    p10[u] = p[kTilePitch];
-                                    p11[u] = p[kTilePitch + 1];
-                                }
-                            } else {
-#pragma unroll
-                                for (int u = 0; u < 8; u++) {
-                                    // clamped so that idle lanes stay inside the frame; 32 loads in flight per lane
-                                    const int ry = min(max(ay[u], 0), nrows1 - 1), rx = min(max(ax[u], 0), ncols1 - 1);
-                                    // the two taps of an image row come in ONE unaligned 16-bit load: the gathers are
-                                    // bound by cache lines touched per wave instruction, so halving the instructions
-                                    // halves the texture-addresser time
-                                    const uint8_t* p = img + (uint32_t)(ry * W + rx);
-                                    uint16_t t0, t1;
-                                    __builtin_memcpy(&t0, p, 2);
-                                    __builtin_memcpy(&t1, p + W, 2);
-                                    p00[u] = t0 & 255;
-                                    p01[u] = t0 >> 8;
-                                    p10[u] = t1 & 255;
-                                    p11[u] = t1 >> 8;
-                                }
-                            }
-#pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                const float a = (float)(qx[u] - ax[u]), b = (float)(qy[u] - ay[u]);
-                                const float oma = 1.f - a, omb = 1.f - b;
-                                float v = (float)p00[u] * oma * omb;
-                                v = v + (float)p01[u] * a * omb;
-                                v = v + (float)p10[u] * oma * b;
-                                v = v + (float)p11[u] * a * b;
-                                S[u] = (int)(uint8_t)d_cvRoundF(v);
-                            }
-                        } else {
-#pragma unroll 1
-                            for (int u = 0; u < 8; u++)
-                                S[u] = active ? sample_pixel_tile(img, W, ncols1, nrows1, qx[u], qy[u], tile, use_lds, x0, y0, x1, y1) : 0;
-                        }
-                        if (area_fast) {
-#pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                iacc += S[u];
-                                if (--left == 0) {
-                                    if (active) s_rowint[i * (kPatch + 1) + c] = iacc;
-                                    c++;
-                                    iacc = 0;
-                                    left = iscale;
-                                }
-                            }
-                        } else {
-#pragma unroll
-                            for (int u = 0; u < 8; u++) {
-                                const PixTab t = s_pix[j0 + jj + u];
-                                const float Sf = (float)S[u];
-                                facc += Sf * t.w_cur;
-                                if (__builtin_amdgcn_readfirstlane(t.end)) {  // same column in every lane
-                                    if (active) s_rowbuf[i * (kPatch + 1) + c] = facc;
-                                    c++;
-                                    facc = Sf * t.w_next;
-                                }
-                            }
-                        }
-                    }
-                    for (; jj < tj; jj++) {  // tail of the last tile
-                        const int Sv = active ? sample_pixel_tile(img, W, ncols1, nrows1, px, py, tile, use_lds, x0, y0, x1, y1) : 0;
-                        px += dcos;
-                        py -= dsin;
-                        if (area_fast) {
-                            iacc += Sv;
-                            if (--left == 0) {
-                                if (active) s_rowint[i * (kPatch + 1) + c] = iacc;
-                                c++;
-                                iacc = 0;
-                                left = iscale;
-                            }
-                        } else {
-                            const PixTab t = s_pix[j0 + jj];
-                            const float Sf = (float)Sv;
-                            facc += Sf * t.w_cur;
-                            if (__builtin_amdgcn_readfirstlane(t.end)) {
-                                if (active) s_rowbuf[i * (kPatch + 1) + c] = facc;
-                                c++;
-                                facc = Sf * t.w_next;
-                            }
-                        }
+                } else {
+                    const PixTab t = s_pix[j];
+                    const float Sf = (float)Sv;
+                    facc += Sf * t.w_cur;
+                    if (t.end) {
+                        s_rowbuf[i * (kPatch + 1) + c] = facc;
+                        c++;
+                        facc = Sf * t.w_next;
                     }
                 }
             }
