@@ -3,17 +3,19 @@
 // Replaces SURF::create(50,4,3,false,false)->detectAndCompute(img, noArray(), kps, desc)
 // (reference: include/visual_odometry/camera_utility.hpp:746-750).
 //
-// Kernels (all batched over frames, blockIdx.y = frame):
-//   k_colsum + k_integral  : u8 image -> int32 integral image, banded two-level scan
-//   k_hessian_layer        : det/trace of one layer (inspection entry point only)
-//   k_hessian_nms          : fused box-filter Hessian (all 5 layers of an octave into LDS),
-//                            3x3x3 non-max suppression, sub-sample interpolation and
-//                            wavefront-ballot compaction of keypoints; nothing but the
-//                            keypoint list is written to HBM
-//   k_rank + k_scatter     : total-order rank sort (KeypointGreater)
-//   k_describe<>           : orientation + 64-float descriptor, one wavefront per keypoint (four for windows > 128 px),
-//                            rotated window sampled row-per-lane straight into the
-//                            INTER_AREA row accumulators held in LDS
+// Kernels (all batched over frames):
+//   k_colsum, k_colsum_scan, k_integral : u8 image -> int32 integral image, banded two-level scan
+//   k_hessian_layer                    : det/trace of one layer (inspection entry point only)
+//   k_hessian_nms_fused / _lds         : box-filter Hessian of the 5 layers of an octave for one sample tile, integral
+//                                        patch staged in LDS (octaves 0 and 1; taps from L1/L2 for octaves 2-3), two-pass
+//                                        3x3x3 non-max suppression with an LDS candidate queue, sub-sample interpolation,
+//                                        wavefront-ballot compaction; only the keypoint list is written to HBM
+//   k_sort_bitonic (k_rank + k_scatter) : KeypointGreater order, bitonic in LDS (rank sort above 16384 keypoints)
+//   k_orientation                      : dominant orientation, one wavefront per keypoint
+//   k_quads, k_classify_*              : 2x2 footprint image; window-class work lists sorted by (frame, tile)
+//   k_describe_tiled<>                 : 64-float descriptor; rotated window sampled in compact 2-D gather blocks from
+//                                        exact closed-form coordinates, INTER_AREA decimation streamed through LDS
+//   k_describe<>                       : the reference's sequential walk, fallback for the rare inexact windows
 // Arithmetic follows the order of operations of SURVEY.md Appendix A exactly; the file is
 // compiled with -ffp-contract=off so that every float/double operation rounds once.
 #include "vo_common.hpp"
