@@ -47,8 +47,15 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        # RCCL ("nccl") is the backend of the real runs; VO_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on
+        # one GPU (RCCL refuses two ranks on the same device)
+        backend = os.environ.get("VO_BENCH_BACKEND", "nccl")
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    coll_dev = "cuda" if world > 1 and os.environ.get("VO_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
     dev = local_rank if torch.cuda.device_count() > local_rank else 0
     torch.cuda.set_device(dev)
 
@@ -83,7 +90,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
 
@@ -92,7 +99,7 @@ def main():
 
     outs = [batch.get(i) for i in range(args.batch)]
     rec_local = shard.pack_records(outs)
-    rec_all = shard.gather_records(rec_local, args.batch * world, rank, world, device="cuda" if world > 1 else "cpu")
+    rec_all = shard.gather_records(rec_local, args.batch * world, rank, world, device=coll_dev)
 
     # PCIe-inclusive rate (reported beside `value`, never as `value`): every step uploads both frames of every pair from
     # host memory and reads the result records back.  Two batches on two contexts (= two HIP streams) alternate, so the
