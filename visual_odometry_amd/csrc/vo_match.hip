@@ -92,29 +92,49 @@ __global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ de
     const float4* __restrict__ descT = descT_base + (size_t)fb * (cap / 32) * 8 * 64;
     const float* __restrict__ nrm = nrm_base + (size_t)fb * cap;
 
-    for (int t = sp; t < ntiles; t += kSplit) {
-        const float4* tp = descT + (size_t)t * 8 * 64 + lane;
-        float4 a4[8];
+    // Operands of a tile come in two halves of four float4 per lane; each half is re-loaded for the NEXT tile right after
+    // its MFMAs were issued, so the loads fly under the other half's MFMAs and the top-2 update (register budget:
+    // 2 x 16 operand registers instead of 32 + 32 for a whole-tile double buffer).
+    float4 ha[4], hb[4];
+    float an_next = 0.f;
+    if (sp < ntiles) {
+        const float4* tp = descT + (size_t)sp * 8 * 64 + lane;
 #pragma unroll
-        for (int s4 = 0; s4 < 8; s4++) a4[s4] = tp[s4 * 64];
-        const float an = (h == 0) ? nrm[t * 32 + l31] : 0.f;
+        for (int s4 = 0; s4 < 4; s4++) {
+            ha[s4] = tp[s4 * 64];
+            hb[s4] = tp[(s4 + 4) * 64];
+        }
+        an_next = (h == 0) ? nrm[sp * 32 + l31] : 0.f;
+    }
+    for (int t = sp; t < ntiles; t += kSplit) {
+        const float an = an_next;
+        const bool more = t + kSplit < ntiles;
+        const float4* tn = descT + (size_t)(more ? t + kSplit : t) * 8 * 64 + lane;
         f32x16 acc0, acc1;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             acc0[r] = 0.f;
             acc1[r] = 0.f;
         }
+#define VO_MFMA4(A, S4)                                                                               \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, bq[0][4 * (S4) + 0], acc0, 0, 0, 0);              \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, bq[1][4 * (S4) + 0], acc1, 0, 0, 0);              \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, bq[0][4 * (S4) + 1], acc0, 0, 0, 0);              \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, bq[1][4 * (S4) + 1], acc1, 0, 0, 0);              \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, bq[0][4 * (S4) + 2], acc0, 0, 0, 0);              \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, bq[1][4 * (S4) + 2], acc1, 0, 0, 0);              \
+    acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, bq[0][4 * (S4) + 3], acc0, 0, 0, 0);              \
+    acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, bq[1][4 * (S4) + 3], acc1, 0, 0, 0);
 #pragma unroll
-        for (int s4 = 0; s4 < 8; s4++) {
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].x, bq[0][4 * s4 + 0], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].x, bq[1][4 * s4 + 0], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].y, bq[0][4 * s4 + 1], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].y, bq[1][4 * s4 + 1], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].z, bq[0][4 * s4 + 2], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].z, bq[1][4 * s4 + 2], acc1, 0, 0, 0);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].w, bq[0][4 * s4 + 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[s4].w, bq[1][4 * s4 + 3], acc1, 0, 0, 0);
-        }
+        for (int s4 = 0; s4 < 4; s4++) { VO_MFMA4(ha[s4], s4) }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) ha[s4] = tn[s4 * 64];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) { VO_MFMA4(hb[s4], s4 + 4) }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) hb[s4] = tn[(s4 + 4) * 64];
+#undef VO_MFMA4
+        an_next = (h == 0) ? nrm[(more ? t + kSplit : t) * 32 + l31] : 0.f;
         // one more k-step adds -0.5*||b_i||^2 to every column of row i
         acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(an, 1.0f, acc0, 0, 0, 0);
         acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(an, 1.0f, acc1, 0, 0, 0);
