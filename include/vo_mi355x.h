@@ -238,6 +238,34 @@ int vo_abs_diff3(const double a[3], const double b[3], int is_angle, double out[
 int vo_estimate_twist(double dt, const double R[9], const double t[3], double sf, const double rpy[3], const double Rbc[9],
                       int motion2d, double lin[3], double ang[3]);
 
+/* ---- N2: get_image, camera_utility.hpp:147-179 -- the per-frame preprocessing of the node -----------
+ * resize(INTER_AREA) :119-136 -> undistort(K, dist) :155 -> cvtColor(COLOR_RGB2GRAY) on the node's BGR frames :160 ->
+ * CLAHE(clip 16, 8 x 8 tiles) :165-169, all on the device.  One vo_prep holds the maps and tables of one camera.   */
+typedef struct vo_prep vo_prep;
+typedef struct vo_prep_params {
+    int32_t src_rows, src_cols;   /* size of the incoming BGR8 frames                                             */
+    int32_t dst_rows, dst_cols;   /* desired_size (:151); equal to the source size = no resize (:125)             */
+    double K[9];                  /* camera matrix of the RESIZED frames, i.e. after vo_update_camera_matrix       */
+    double dist[4];               /* k1 k2 p1 p2 (the node's yaml holds four coefficients)                        */
+    double clip_limit;            /* CLIP_LIMIT = 16.0, camera_utility.hpp:10                                     */
+    int32_t tiles_x, tiles_y;     /* createCLAHE() default 8 x 8                                                  */
+} vo_prep_params;
+/* updateCameraMatrix, camera_utility.hpp:138-145: diag(RW, RH, 1) * K                                            */
+int vo_update_camera_matrix(int src_rows, int src_cols, int dst_rows, int dst_cols, const double K[9], double K_out[9]);
+int vo_prep_create(vo_ctx* ctx, const vo_prep_params* p, vo_prep** out);
+void vo_prep_destroy(vo_prep* pp);
+/* get_image on one frame: host BGR8 in, host gray8 out (synchronous)                                              */
+int vo_prep_run(vo_prep* pp, const uint8_t* bgr, size_t step, uint8_t* gray, size_t gray_step);
+/* get_image with the result left on the device as frame `frame` of a batch (frame = 2 * pair + {0, 1} in a pair
+ * batch, the frame index in a sequence batch); asynchronous like vo_batch_set_pair.  The pair's K still comes from
+ * vo_batch_set_k / vo_seq_set_pair.                                                                               */
+int vo_prep_to_batch(vo_prep* pp, const uint8_t* bgr, size_t step, vo_batch* b, int frame);
+/* K of a pair whose frames arrive through vo_prep_to_batch (pair batches)                                         */
+int vo_batch_set_k(vo_batch* b, int pair, const double K[9]);
+/* inspection of the last frame's intermediates (tests): what = 0 resized BGR [dst_rows][dst_cols][3], 1 undistorted
+ * BGR, 2 gray, 3 CLAHE look-up tables [tiles_y][tiles_x][256], 4 map1 int16 [dst_rows][dst_cols][2], 5 map2 uint16 */
+int vo_prep_fetch(vo_prep* pp, int what, void* dst, size_t bytes);
+
 /* Per-stage device timing (HIP events on the context's compute stream).  Enable, run,
  * sync, then read.  Stage names: vo_stage_name(i), i in [0, vo_stage_count()).           */
 int vo_profile_enable(vo_ctx* ctx, int on);

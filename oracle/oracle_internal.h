@@ -62,5 +62,15 @@ void triangulate(const double P0[12], const double P1[12], const double* x1, con
 int triang_points(const vo_params& P, const float* in1, const float* in2, int n, const double R[9], const double t[3],
                   const double K[9], std::vector<double>& Xk /*[m][3]*/);
 
+
+// oracle_prep.cpp (N2: get_image, camera_utility.hpp:147-179)
+void resize_area_bgr(const uint8_t* src, int srows, int scols, size_t sstep, uint8_t* dst, int drows, int dcols);
+void bilinear_tab_i(int16_t* tab /*[1024][4]*/);
+void undistort_maps(int rows, int cols, const double K[9], const double dist[4], int16_t* map1, uint16_t* map2);
+void remap_bilinear_bgr(const uint8_t* src, int rows, int cols, const int16_t* map1, const uint16_t* map2, const int16_t* wtab,
+                        uint8_t* dst);
+void rgb2gray_u8(const uint8_t* src, int rows, int cols, uint8_t* dst);
+void clahe_u8(const uint8_t* src, int rows, int cols, double clip_limit, int tiles_x, int tiles_y, uint8_t* dst, uint8_t* lut_out);
+
 }  // namespace vo_oracle
 #endif

@@ -270,4 +270,30 @@ int vo_oracle_pair(const vo_params* p, const uint8_t* img1, size_t step1, const 
     return VO_OK;
 }
 
+int vo_oracle_prep(const vo_prep_params* p, const uint8_t* bgr, size_t step, uint8_t* resized, uint8_t* undist,
+                   uint8_t* gray0, uint8_t* lut, int16_t* map1, uint16_t* map2, uint8_t* gray) {
+    if (!p || !bgr || !gray) return VO_ERR_INVALID_ARG;
+    const int R = p->dst_rows, C = p->dst_cols;
+    if (R > p->src_rows || C > p->src_cols || R < 1 || C < 1) return VO_ERR_UNSUPPORTED;
+    const size_t px = (size_t)R * C;
+    std::vector<uint8_t> rs(px * 3), ud(px * 3), g0(px);
+    if (R != p->src_rows || C != p->src_cols)
+        resize_area_bgr(bgr, p->src_rows, p->src_cols, step, rs.data(), R, C);
+    else
+        for (int r = 0; r < R; r++) std::memcpy(rs.data() + (size_t)r * C * 3, bgr + (size_t)r * step, (size_t)C * 3);
+    std::vector<int16_t> m1(px * 2), wtab(1024 * 4);
+    std::vector<uint16_t> m2(px);
+    bilinear_tab_i(wtab.data());
+    undistort_maps(R, C, p->K, p->dist, m1.data(), m2.data());
+    remap_bilinear_bgr(rs.data(), R, C, m1.data(), m2.data(), wtab.data(), ud.data());
+    rgb2gray_u8(ud.data(), R, C, g0.data());
+    clahe_u8(g0.data(), R, C, p->clip_limit, p->tiles_x, p->tiles_y, gray, lut);
+    if (resized) std::memcpy(resized, rs.data(), rs.size());
+    if (undist) std::memcpy(undist, ud.data(), ud.size());
+    if (gray0) std::memcpy(gray0, g0.data(), g0.size());
+    if (map1) std::memcpy(map1, m1.data(), m1.size() * sizeof(int16_t));
+    if (map2) std::memcpy(map2, m2.data(), m2.size() * sizeof(uint16_t));
+    return VO_OK;
+}
+
 }  // extern "C"

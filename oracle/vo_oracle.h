@@ -56,6 +56,12 @@ int vo_oracle_triang_points(const vo_params* p, const float* in1xy, const float*
 int vo_oracle_pair(const vo_params* p, const uint8_t* img1, size_t step1, const uint8_t* img2, size_t step2,
                    int rows, int cols, const double K[9], vo_pair_out* out);
 
+/* N2: get_image (camera_utility.hpp:147-179) on one BGR8 frame.  Every output pointer but gray may be NULL:
+ * resized / undist [dst_rows][dst_cols][3], gray0 (before CLAHE) and gray [dst_rows][dst_cols], lut [ty][tx][256],
+ * map1 int16 [dst_rows][dst_cols][2], map2 uint16 [dst_rows][dst_cols].                                          */
+int vo_oracle_prep(const vo_prep_params* p, const uint8_t* bgr, size_t step, uint8_t* resized, uint8_t* undist,
+                   uint8_t* gray0, uint8_t* lut, int16_t* map1, uint16_t* map2, uint8_t* gray);
+
 #ifdef __cplusplus
 }
 #endif

@@ -211,3 +211,16 @@ def pair(img1, img2, K, params=None):
     _chk(lib.vo_oracle_pair(C.byref(params) if params else None, _p(img1, u8p), C.c_size_t(img1.strides[0]), _p(img2, u8p), C.c_size_t(img2.strides[0]),
                             h, w, _p(K, f64p), C.byref(out)))
     return out
+
+
+def prep(params, bgr):
+    """get_image restatement: returns dict(resized, undist, gray0, lut, map1, map2, gray)."""
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    R, Cc = params.dst_rows, params.dst_cols
+    o = dict(resized=np.zeros((R, Cc, 3), np.uint8), undist=np.zeros((R, Cc, 3), np.uint8), gray0=np.zeros((R, Cc), np.uint8),
+             lut=np.zeros((params.tiles_y, params.tiles_x, 256), np.uint8), map1=np.zeros((R, Cc, 2), np.int16),
+             map2=np.zeros((R, Cc), np.uint16), gray=np.zeros((R, Cc), np.uint8))
+    _chk(lib.vo_oracle_prep(C.byref(params), _p(bgr, u8p), C.c_size_t(bgr.strides[0]), _p(o["resized"], u8p), _p(o["undist"], u8p),
+                            _p(o["gray0"], u8p), _p(o["lut"], u8p), o["map1"].ctypes.data_as(C.c_void_p),
+                            o["map2"].ctypes.data_as(C.c_void_p), _p(o["gray"], u8p)))
+    return o

@@ -1,0 +1,197 @@
+"""N2 (get_image, camera_utility.hpp:147-179): known-answer tests of the CPU restatement oracle/oracle_prep.cpp.
+
+PARITY UNPINNED: the reference ships no fixtures for its preprocessing and OpenCV is not available here; the oracle is
+checked against independent numpy statements of the published algorithms and analytic cases, not against OpenCV output.
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from visual_odometry_amd import synth
+from visual_odometry_amd._abi import VoPrepParams
+
+
+def make_params(src_shape, dst_shape, K, dist, clip=16.0, tiles=(8, 8)):
+    p = VoPrepParams()
+    p.src_rows, p.src_cols = src_shape
+    p.dst_rows, p.dst_cols = dst_shape
+    p.K[:] = [float(v) for v in np.asarray(K, float).ravel()]
+    p.dist[:] = [float(v) for v in dist]
+    p.clip_limit = clip
+    p.tiles_x, p.tiles_y = tiles
+    return p
+
+
+K_ID = np.array([[300.0, 0, 80.0], [0, 300.0, 60.0], [0, 0, 1.0]])
+
+
+def test_resize_integer_scales_are_exact_box_means():
+    img = synth.bgr_frame(96, 128, 1)
+    o = O.prep(make_params((96, 128), (48, 64), K_ID, [0, 0, 0, 0]), img)
+    box = img.reshape(48, 2, 64, 2, 3).astype(np.int64).sum(axis=(1, 3))
+    assert np.array_equal(o["resized"], (box + 2) >> 2)  # ResizeAreaFast 2 x 2: (sum + 2) >> 2
+    o = O.prep(make_params((96, 128), (24, 32), K_ID, [0, 0, 0, 0]), img)
+    box = img.reshape(24, 4, 32, 4, 3).astype(np.int64).sum(axis=(1, 3))
+    expect = np.rint(box.astype(np.float32) * np.float32(1.0 / 16)).astype(np.uint8)  # cvRound(sum * (1.f / area)), half to even
+    assert np.array_equal(o["resized"], expect)
+
+
+def test_resize_fractional_scale_is_the_area_average():
+    img = synth.bgr_frame(103, 160, 2)  # 103 -> 25 rows: scale 4.12; 160 -> 40 columns: 4.0 but generic path (one axis fractional)
+    o = O.prep(make_params((103, 160), (25, 40), K_ID, [0, 0, 0, 0]), img)
+    sy = 103 / 25
+    ref = np.zeros((25, 40, 3))
+    for dy in range(25):
+        a, b = dy * sy, min((dy + 1) * sy, 103)
+        w = np.clip(np.minimum(np.arange(103) + 1, b) - np.maximum(np.arange(103), a), 0, None)
+        rows = (img.astype(np.float64) * w[:, None, None]).sum(axis=0) / w.sum()
+        ref[dy] = rows.reshape(40, 4, 3).mean(axis=1)
+    d = np.abs(o["resized"].astype(np.float64) - ref)
+    assert d.max() <= 0.5 + 1e-3  # correctly rounded area mean up to float accumulation
+    const = np.full((103, 160, 3), 201, np.uint8)
+    assert np.all(O.prep(make_params((103, 160), (25, 40), K_ID, [0, 0, 0, 0]), const)["resized"] == 201)
+
+
+def test_no_resize_when_sizes_match():
+    img = synth.bgr_frame(120, 160, 3)
+    o = O.prep(make_params((120, 160), (120, 160), K_ID, [0, 0, 0, 0]), img)
+    assert np.array_equal(o["resized"], img)  # desiredResize returns img itself, camera_utility.hpp:133
+
+
+def test_undistort_without_distortion_is_the_identity():
+    img = synth.bgr_frame(120, 160, 4)
+    o = O.prep(make_params((120, 160), (120, 160), K_ID, [0, 0, 0, 0]), img)
+    yy, xx = np.mgrid[0:120, 0:160]
+    assert np.array_equal(o["map1"][..., 0], xx) and np.array_equal(o["map1"][..., 1], yy)
+    assert not o["map2"].any()
+    # weight cell (0, 0) is {32767, 0, 0, 1}: still the identity on bytes
+    assert np.array_equal(o["undist"], img)
+
+
+def test_undistort_maps_follow_the_distortion_model():
+    K = np.array([[576.4, 0, 320.5], [0, 566.0, 252.6], [0, 0, 1.0]])
+    dist = synth.DIST_RAPALLO
+    img = synth.bgr_frame(505, 640, 5)
+    o = O.prep(make_params((505, 640), (505, 640), K, dist), img)
+    yy, xx = np.mgrid[0:505, 0:640].astype(np.float64)
+    x, y = (xx - K[0, 2]) / K[0, 0], (yy - K[1, 2]) / K[1, 1]
+    r2 = x * x + y * y
+    kr = 1 + dist[0] * r2 + dist[1] * r2 * r2
+    u = K[0, 0] * (x * kr + 2 * dist[2] * x * y + dist[3] * (r2 + 2 * x * x)) + K[0, 2]
+    v = K[1, 1] * (y * kr + dist[2] * (r2 + 2 * y * y) + 2 * dist[3] * x * y) + K[1, 2]
+    mu = o["map1"][..., 0].astype(np.int64) * 32 + (o["map2"] & 31)
+    mv = o["map1"][..., 1].astype(np.int64) * 32 + (o["map2"] >> 5)
+    # 1/32-pixel quantisation; the incremental walk and the closed form agree far below one quantum
+    assert np.abs(mu - u * 32).max() <= 0.5 + 1e-6 and np.abs(mv - v * 32).max() <= 0.5 + 1e-6
+    # bilinear remap of the maps, in float, is within one grey level of the fixed-point result (inside the frame)
+    sx, sy = o["map1"][..., 0].astype(np.int64), o["map1"][..., 1].astype(np.int64)
+    inside = (sx >= 0) & (sy >= 0) & (sx < 639) & (sy < 504)
+    fx, fy = (o["map2"] & 31) / 32.0, (o["map2"] >> 5) / 32.0
+    sxc, syc = np.clip(sx, 0, 638), np.clip(sy, 0, 503)
+    f = img.astype(np.float64)
+    ref = (f[syc, sxc] * ((1 - fx) * (1 - fy))[..., None] + f[syc, sxc + 1] * (fx * (1 - fy))[..., None]
+           + f[syc + 1, sxc] * ((1 - fx) * fy)[..., None] + f[syc + 1, sxc + 1] * (fx * fy)[..., None])
+    assert np.abs(o["undist"].astype(np.float64) - ref)[inside].max() <= 0.5 + 1e-3
+    # sources outside the frame read the constant border 0
+    out = (sx < -1) | (sy < -1) | (sx >= 640) | (sy >= 505)
+    assert np.all(o["undist"][out] == 0)
+
+
+def test_gray_weights_the_first_channel_as_red():
+    img = np.zeros((16, 16, 3), np.uint8)
+    img[..., 0] = 200  # blue in the node's BGR frames, weighted 0.299 by COLOR_RGB2GRAY (camera_utility.hpp:160)
+    o = O.prep(make_params((16, 16), (16, 16), K_ID, [0, 0, 0, 0], tiles=(2, 2)), img)
+    assert np.all(o["gray0"] == (200 * 9798 + 16384) >> 15)
+    rng = np.random.default_rng(6)
+    img = rng.integers(0, 256, (16, 16, 3), dtype=np.uint8)
+    o = O.prep(make_params((16, 16), (16, 16), K_ID, [0, 0, 0, 0], tiles=(2, 2)), img)
+    i = img.astype(np.int64)
+    assert np.array_equal(o["gray0"], (i[..., 0] * 9798 + i[..., 1] * 19235 + i[..., 2] * 3735 + 16384) >> 15)
+
+
+def clahe_numpy(g, clip_limit, tx, ty):
+    """Independent statement of CLAHE (Zuiderveld; OpenCV's tile/clip/blend conventions)."""
+    rows, cols = g.shape
+    er, ec = rows, cols
+    if rows % ty or cols % tx:
+        er, ec = rows + ty - rows % ty, cols + tx - cols % tx
+    ext = np.pad(g, ((0, er - rows), (0, ec - cols)), mode="reflect")
+    th, tw = er // ty, ec // tx
+    area = th * tw
+    clip = max(int(clip_limit * area / 256), 1) if clip_limit > 0 else 0
+    lut = np.zeros((ty, tx, 256), np.uint8)
+    for j in range(ty):
+        for i in range(tx):
+            h = np.bincount(ext[j * th:(j + 1) * th, i * tw:(i + 1) * tw].ravel(), minlength=256).astype(np.int64)
+            if clip:
+                excess = int(np.maximum(h - clip, 0).sum())
+                h = np.minimum(h, clip) + excess // 256
+                res = excess % 256
+                if res:
+                    step = max(256 // res, 1)
+                    idx = np.arange(0, 256, step)[:res]
+                    h[idx] += 1
+            lut[j, i] = np.clip(np.rint(np.cumsum(h).astype(np.float32) * np.float32(255.0 / area)), 0, 255)
+    out = np.zeros_like(g)
+    f32 = np.float32
+    for y in range(rows):
+        tyf = f32(y) * f32(1.0 / th) - f32(0.5)
+        y1 = int(np.floor(tyf))
+        ya = f32(tyf - f32(y1))
+        y2 = min(y1 + 1, ty - 1)
+        y1 = max(y1, 0)
+        for x in range(cols):
+            txf = f32(x) * f32(1.0 / tw) - f32(0.5)
+            x1 = int(np.floor(txf))
+            xa = f32(txf - f32(x1))
+            x2 = min(x1 + 1, tx - 1)
+            x1 = max(x1, 0)
+            v = g[y, x]
+            top = f32(lut[y1, x1, v]) * (f32(1) - xa) + f32(lut[y1, x2, v]) * xa
+            bot = f32(lut[y2, x1, v]) * (f32(1) - xa) + f32(lut[y2, x2, v]) * xa
+            out[y, x] = np.clip(np.rint(top * (f32(1) - ya) + bot * ya), 0, 255)
+    return out, lut
+
+
+@pytest.mark.parametrize("shape,tiles,clip", [((64, 96), (4, 4), 16.0), ((61, 96), (8, 8), 16.0), ((40, 50), (4, 2), 2.0), ((32, 32), (2, 2), 0.0)])
+def test_clahe_against_an_independent_statement(shape, tiles, clip):
+    rows, cols = shape
+    img = synth.bgr_frame(rows, cols, 7 + rows)
+    o = O.prep(make_params(shape, shape, K_ID, [0, 0, 0, 0], clip=clip, tiles=tiles), img)
+    ref, lut = clahe_numpy(o["gray0"], clip, tiles[0], tiles[1])
+    assert np.array_equal(o["lut"], lut)
+    assert np.array_equal(o["gray"], ref)
+
+
+def test_clahe_pads_both_axes_when_one_needs_it():
+    # 505 rows are not a multiple of 8, 640 columns are: OpenCV still pads the columns by a full 8 (648 x 512, tiles 81 x 64)
+    img = synth.bgr_frame(505, 640, 8)
+    o = O.prep(make_params((505, 640), (505, 640), K_ID, [0, 0, 0, 0]), img)
+    g = o["gray0"]
+    ext = np.pad(g, ((0, 7), (0, 8)), mode="reflect")
+    h = np.bincount(ext[0:64, 7 * 81:8 * 81].ravel(), minlength=256)
+    clip = int(16.0 * 81 * 64 / 256)
+    excess = int(np.maximum(h - clip, 0).sum())
+    h = np.minimum(h, clip) + excess // 256
+    res = excess % 256
+    if res:
+        h[np.arange(0, 256, max(256 // res, 1))[:res]] += 1
+    lut = np.clip(np.rint(np.cumsum(h).astype(np.float32) * np.float32(255.0 / (81 * 64))), 0, 255).astype(np.uint8)
+    assert np.array_equal(o["lut"][0, 7], lut)
+    assert o["gray"].std() > g.std()  # contrast goes up
+
+
+def test_full_chain_at_the_rapallo_size():
+    """2560 x 2056 -> 640 x 505 with the rapallo camera: shapes, map sanity, deterministic output."""
+    img = synth.bgr_frame(2056, 2560, 9)
+    K = np.diag([640 / 2560, 505 / 2056, 1.0]) @ synth.K_RAPALLO_FULL  # updateCameraMatrix, camera_utility.hpp:138
+    p = make_params((2056, 2560), (505, 640), K, synth.DIST_RAPALLO)
+    a, b = O.prep(p, img), O.prep(p, img)
+    assert np.array_equal(a["gray"], b["gray"])
+    assert a["gray"].shape == (505, 640)
+    # the distortion is tens of pixels at the corners (k2 = 0.34), nothing at the principal point
+    cy, cx = int(round(K[1, 2])), int(round(K[0, 2]))
+    assert abs(int(a["map1"][cy, cx, 0]) - cx) <= 1 and abs(int(a["map1"][cy, cx, 1]) - cy) <= 1
+    assert 20 <= abs(int(a["map1"][0, 0, 0])) + abs(int(a["map1"][0, 0, 1])) <= 120  # kr = 1.12 at the corner: ~38 px

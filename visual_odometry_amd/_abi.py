@@ -53,6 +53,14 @@ class VoPairOut(C.Structure):
     ]
 
 
+class VoPrepParams(C.Structure):
+    _fields_ = [
+        ("src_rows", C.c_int32), ("src_cols", C.c_int32), ("dst_rows", C.c_int32), ("dst_cols", C.c_int32),
+        ("K", C.c_double * 9), ("dist", C.c_double * 4), ("clip_limit", C.c_double),
+        ("tiles_x", C.c_int32), ("tiles_y", C.c_int32),
+    ]
+
+
 KP_DTYPE = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"), ("response", "<f4"),
                      ("octave", "<i4"), ("class_id", "<i4")])
 DM_DTYPE = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])

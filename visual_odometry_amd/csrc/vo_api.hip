@@ -92,7 +92,8 @@ static void resolve_timers(vo_ctx* ctx) {
 static const char* kStageNames[ST_COUNT] = {"integral",      "hessian_oct1",  "hessian_oct0_23",    "sort",          "orientation",
                                             "describe_prep", "describe_w768", "describe_w320",      "describe_w128", "describe_w64",
                                             "describe_seq",  "match_prep",    "match_mfma",         "match_select",  "ransac_sample",
-                                            "ransac_solve_score", "ransac_select", "pose",          "triangulate"};
+                                            "ransac_solve_score", "ransac_select", "pose",          "triangulate",
+                                            "prep_resize",   "prep_remap_gray", "prep_clahe"};
 
 extern "C" int vo_stage_count(void) { return ST_COUNT; }
 extern "C" const char* vo_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
@@ -782,6 +783,13 @@ extern "C" int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, siz
     VO_HIP(hipSetDevice(b->ctx->device));
     VO_TRY(stage_frame(b, 2 * pair, img1, step1));
     VO_TRY(stage_frame(b, 2 * pair + 1, img2, step2));
+    init_state(b->h_state[pair], 0, K);
+    b->state_dirty = true;
+    return VO_OK;
+}
+
+extern "C" int vo_batch_set_k(vo_batch* b, int pair, const double K[9]) {
+    if (!b || b->is_seq || pair < 0 || pair >= b->n_pairs || !K) return VO_ERR_INVALID_ARG;
     init_state(b->h_state[pair], 0, K);
     b->state_dirty = true;
     return VO_OK;

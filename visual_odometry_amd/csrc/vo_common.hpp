@@ -108,6 +108,9 @@ enum Stage {
     ST_RANSAC_SELECT,
     ST_POSE,
     ST_TRIANGULATE,
+    ST_PREP_RESIZE,     // vo_prep.hip (N2): INTER_AREA resize
+    ST_PREP_REMAP,      // undistort remap + gray
+    ST_PREP_CLAHE,      // tile look-up tables + blending
     ST_COUNT
 };
 

@@ -286,6 +286,11 @@ class Batch:
         self.ctx._chk(self.ctx.lib.vo_batch_set_pair(self._h, i, _p(img1, u8p), C.c_size_t(img1.strides[0]), _p(img2, u8p),
                                                      C.c_size_t(img2.strides[0]), _p(K, f64p)))
 
+    def set_k(self, i, K):
+        """K of a pair whose frames arrive through Prep.to_batch (vo_batch_set_k)."""
+        K = np.ascontiguousarray(K, np.float64)
+        self.ctx._chk(self.ctx.lib.vo_batch_set_k(self._h, i, _p(K, f64p)))
+
     def run(self):
         self.ctx._chk(self.ctx.lib.vo_batch_run(self._h))
 

@@ -228,3 +228,21 @@ def sequence_scene(h: int, w: int, K: np.ndarray, n_blobs: int, seed: int, poses
         Rw.append(Rk)
         tw.append(tk)
     return SequenceScene(frames, K.copy(), Rw, tw)
+
+
+# rapallo camera of the reference (config/rapallo_camera_params.yaml): 2560 x 2056 frames, desired_size 640 x 505
+K_RAPALLO_FULL = np.array([[2305.66, 0.0, 1281.94], [0.0, 2303.95, 1028.35], [0.0, 0.0, 1.0]])
+DIST_RAPALLO = np.array([0.0626, 0.3415, 0.00312, -0.00555])
+
+
+def bgr_frame(rows: int, cols: int, seed: int, contrast: float = 0.5) -> np.ndarray:
+    """Seeded colour frame [rows, cols, 3] uint8 (BGR order as cv_bridge hands it to the node): low-contrast, blue-green
+    tinted value noise at three scales plus pixel noise - the kind of underwater frame CLAHE is there for."""
+    rng = np.random.default_rng(seed)
+    base = _value_noise(rng, rows, cols, max(rows // 6, 4), 60.0) + _value_noise(rng, rows, cols, max(rows // 40, 2), 35.0)
+    fine = _value_noise(rng, rows, cols, 3, 25.0)
+    out = np.empty((rows, cols, 3), np.uint8)
+    for c, (gain, offs) in enumerate(((1.0, 120.0), (0.85, 105.0), (0.45, 60.0))):
+        ch = offs + contrast * gain * (base + fine + _value_noise(rng, rows, cols, 9, 12.0)) + rng.normal(0.0, 2.0, (rows, cols))
+        out[..., c] = np.clip(np.rint(ch), 0, 255).astype(np.uint8)
+    return out
