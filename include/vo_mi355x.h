@@ -262,6 +262,9 @@ int vo_prep_run(vo_prep* pp, const uint8_t* bgr, size_t step, uint8_t* gray, siz
 int vo_prep_to_batch(vo_prep* pp, const uint8_t* bgr, size_t step, vo_batch* b, int frame);
 /* K of a pair whose frames arrive through vo_prep_to_batch (pair batches)                                         */
 int vo_batch_set_k(vo_batch* b, int pair, const double K[9]);
+/* Measurement hook, no counterpart in the reference: enqueue the four passes `reps` more times on the frame already
+ * resident on the device (no upload), asynchronously on the context's stream -- the "inputs resident in HBM" timing. */
+int vo_prep_rerun(vo_prep* pp, int reps);
 /* inspection of the last frame's intermediates (tests): what = 0 resized BGR [dst_rows][dst_cols][3], 1 undistorted
  * BGR, 2 gray, 3 CLAHE look-up tables [tiles_y][tiles_x][256], 4 map1 int16 [dst_rows][dst_cols][2], 5 map2 uint16 */
 int vo_prep_fetch(vo_prep* pp, int what, void* dst, size_t bytes);

@@ -48,6 +48,11 @@ def test_ragged_sizes_and_tile_grids(ctx):
     _check(ctx, (131, 173), (131, 97), K_SMALL * [[0.6], [1.0], [1]], [0.0, 0.0, 0.0, 0.0], 32, tiles=(4, 2))  # one axis only
     _check(ctx, (64, 64), (32, 32), K_SMALL * [[0.2], [0.25], [1]], [0.0, 0.0, 0.0, 0.0], 33, clip=0.0, tiles=(2, 2))  # clip off
     _check(ctx, (200, 300), (100, 150), K_SMALL, [2.5, 1.0, 0.2, 0.2], 34, clip=1.0, tiles=(16, 16))        # sources far outside the frame
+    _check(ctx, (333, 512), (61, 93), K_SMALL * [[0.3], [0.5], [1]], [0.1, 0.0, 0.0, 0.0], 38)                 # staged resize, 8 x 8 taps
+    _check(ctx, (480, 640), (200, 270), K_SMALL * [[0.9], [1.6], [1]], [0.0, 0.0, 0.01, 0.0], 39)              # staged resize, 4 x 4 taps
+    _check(ctx, (330, 520), (41, 64), K_SMALL * [[0.4], [0.3], [1]], [0.1, 0.0, 0.0, 0.0], 35, tiles=(4, 4))   # scale ~8.1: any-scale kernel
+    _check(ctx, (400, 350), (40, 70), K_SMALL * [[0.4], [0.3], [1]], [0.1, 0.0, 0.0, 0.0], 36, tiles=(2, 2))   # 5 x 10 integer boxes
+    _check(ctx, (300, 450), (60, 150), K_SMALL * [[0.8], [0.5], [1]], [0.0, 0.1, 0.0, 0.0], 37, tiles=(3, 5))  # 3 x 5 boxes, odd tile grid
 
 
 def test_extreme_images(ctx):

@@ -50,59 +50,130 @@ void area_taps(int ssize, int dsize, double scale, std::vector<AreaTap>& tap, st
 
 __device__ __forceinline__ uint8_t sat_u8(int v) { return (uint8_t)min(max(v, 0), 255); }
 
-// ResizeArea (fractional scale): float accumulation in table order, rows outer
+// ResizeArea (fractional scale): float accumulation in table order, rows outer.  One lane per destination BYTE (pixel,
+// channel): neighbouring lanes read neighbouring source bytes.  This is the any-scale form; its loops are serial chains
+// of dependent loads, so the scales the node uses go through k_resize_area_u below.
 __global__ __launch_bounds__(256) void k_resize_area(const uint8_t* __restrict__ src, int sstep, const AreaTap* __restrict__ xt,
                                                       const int* __restrict__ xo, const AreaTap* __restrict__ yt,
                                                       const int* __restrict__ yo, uint8_t* __restrict__ dst, int drows, int dcols) {
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dcols) return;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (e >= dcols * 3) return;
+    const int dx = e / 3, c = e - dx * 3;
     const int k0 = xo[dx], k1 = xo[dx + 1];
-    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
-    bool first = true;
+    float s = 0.f;
     for (int j = yo[dy]; j < yo[dy + 1]; j++) {
         const float beta = yt[j].alpha;
-        const uint8_t* S = src + (size_t)yt[j].si * sstep;
-        float b0 = 0.f, b1 = 0.f, b2 = 0.f;
-        for (int k = k0; k < k1; k++) {
-            const float a = xt[k].alpha;
-            const uint8_t* p = S + xt[k].si * 3;
-            b0 += p[0] * a;
-            b1 += p[1] * a;
-            b2 += p[2] * a;
-        }
-        if (first) {
-            s0 = beta * b0, s1 = beta * b1, s2 = beta * b2;
-            first = false;
-        } else {
-            s0 += beta * b0, s1 += beta * b1, s2 += beta * b2;
-        }
+        const uint8_t* S = src + (size_t)yt[j].si * sstep + c;
+        float b = 0.f;
+        for (int k = k0; k < k1; k++) b += S[xt[k].si * 3] * xt[k].alpha;
+        s += beta * b;  // 0.f + x == x: the first row needs no special case
     }
-    uint8_t* D = dst + ((size_t)dy * dcols + dx) * 3;
-    D[0] = sat_u8((int)rintf(s0));
-    D[1] = sat_u8((int)rintf(s1));
-    D[2] = sat_u8((int)rintf(s2));
+    dst[(size_t)dy * dcols * 3 + e] = sat_u8((int)rintf(s));
 }
 
-// ResizeAreaFast (integer scale): exact box sums
+// The same sums with at most MX x MY taps per destination byte (the taps of one destination index are consecutive source
+// indices).  Absent taps carry weight 0 and re-read the last valid byte: x + 0.f * v == x exactly for these non-negative
+// sums, so the loops unroll completely and all MX * MY byte loads are in flight at once.
+template <int MX, int MY>
+__global__ __launch_bounds__(256) void k_resize_area_u(const uint8_t* __restrict__ src, int sstep, const AreaTap* __restrict__ xt,
+                                                        const int* __restrict__ xo, const AreaTap* __restrict__ yt,
+                                                        const int* __restrict__ yo, uint8_t* __restrict__ dst, int drows, int dcols) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (e >= dcols * 3) return;
+    const int dx = e / 3, c = e - dx * 3;
+    const int k0 = xo[dx], nx = xo[dx + 1] - k0, j0 = yo[dy], ny = yo[dy + 1] - j0;
+    const int sx0 = xt[k0].si, sy0 = yt[j0].si;
+    float ax[MX], ay[MY];
+#pragma unroll
+    for (int k = 0; k < MX; k++) ax[k] = k < nx ? xt[k0 + k].alpha : 0.f;
+#pragma unroll
+    for (int j = 0; j < MY; j++) ay[j] = j < ny ? yt[j0 + j].alpha : 0.f;
+    const uint8_t* S = src + (size_t)sy0 * sstep + sx0 * 3 + c;
+    uint8_t v[MY][MX];
+#pragma unroll
+    for (int j = 0; j < MY; j++)
+#pragma unroll
+        for (int k = 0; k < MX; k++) v[j][k] = S[(size_t)min(j, ny - 1) * sstep + min(k, nx - 1) * 3];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MY; j++) {
+        float b = 0.f;
+#pragma unroll
+        for (int k = 0; k < MX; k++) b += v[j][k] * ax[k];
+        s += ay[j] * b;
+    }
+    dst[(size_t)dy * dcols * 3 + e] = sat_u8((int)rintf(s));
+}
+
+// k_resize_area_u with the source bytes staged through LDS: one block = 256 consecutive destination bytes of one
+// destination row; the (at most MY) source rows it needs are read once, with aligned 16-byte loads, into LDS and the
+// taps are LDS byte reads.  Needs 16-byte aligned source rows (sstep % 16 == 0): the node's 2560-pixel rows are.
+constexpr int kResizePitch = 2048 + 64;  // bytes of one staged source row: 86 pixels * 7 columns * 3 + alignment slack
+template <int MX, int MY>
+__global__ __launch_bounds__(256) void k_resize_area_lds(const uint8_t* __restrict__ src, int sstep, const AreaTap* __restrict__ xt,
+                                                          const int* __restrict__ xo, const AreaTap* __restrict__ yt,
+                                                          const int* __restrict__ yo, uint8_t* __restrict__ dst, int drows, int dcols) {
+    __shared__ __attribute__((aligned(16))) uint8_t s_row[MY][kResizePitch];
+    const int t = threadIdx.x, e0 = blockIdx.x * 256, dy = blockIdx.y;
+    const int e_last = min(e0 + 255, dcols * 3 - 1);
+    const int j0 = yo[dy], ny = yo[dy + 1] - j0, sy0 = yt[j0].si;
+    const int b_lo = (xt[xo[e0 / 3]].si * 3) & ~15;                        // first staged byte of a source row (16-aligned)
+    const int b_hi = (xt[xo[e_last / 3 + 1] - 1].si * 3 + 3 + 15) & ~15;   // one past the last, rounded up
+    const int chunks = (b_hi - b_lo) >> 4;
+    for (int i = t; i < chunks * ny; i += 256) {
+        const int j = i / chunks, ch = i - j * chunks;
+        *(uint4*)&s_row[j][ch * 16] = *(const uint4*)(src + (size_t)(sy0 + j) * sstep + b_lo + ch * 16);
+    }
+    __syncthreads();
+    const int e = e0 + t;
+    if (e >= dcols * 3) return;
+    const int dx = e / 3, c = e - dx * 3;
+    const int k0 = xo[dx], nx = xo[dx + 1] - k0;
+    const int off = xt[k0].si * 3 + c - b_lo;
+    float ax[MX], ay[MY];
+#pragma unroll
+    for (int k = 0; k < MX; k++) ax[k] = k < nx ? xt[k0 + k].alpha : 0.f;
+#pragma unroll
+    for (int j = 0; j < MY; j++) ay[j] = j < ny ? yt[j0 + j].alpha : 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < MY; j++) {
+        float b = 0.f;
+#pragma unroll
+        for (int k = 0; k < MX; k++) b += s_row[min(j, ny - 1)][off + min(k, nx - 1) * 3] * ax[k];
+        s += ay[j] * b;
+    }
+    dst[(size_t)dy * dcols * 3 + e] = sat_u8((int)rintf(s));
+}
+
+// ResizeAreaFast (integer scale): exact box sums, one lane per destination byte.  IS > 0: square IS x IS boxes unrolled.
+template <int IS>
 __global__ __launch_bounds__(256) void k_resize_area_int(const uint8_t* __restrict__ src, int sstep, int isx, int isy,
                                                           uint8_t* __restrict__ dst, int drows, int dcols) {
-    const int dx = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
-    if (dx >= dcols) return;
-    int s0 = 0, s1 = 0, s2 = 0;
-    for (int y = 0; y < isy; y++) {
-        const uint8_t* p = src + (size_t)(dy * isy + y) * sstep + (size_t)dx * isx * 3;
-        for (int x = 0; x < isx; x++, p += 3) s0 += p[0], s1 += p[1], s2 += p[2];
+    const int e = blockIdx.x * blockDim.x + threadIdx.x, dy = blockIdx.y;
+    if (e >= dcols * 3) return;
+    const int dx = e / 3, c = e - dx * 3;
+    if (IS > 0) isx = isy = IS;
+    int s = 0;
+    const uint8_t* p = src + (size_t)dy * isy * sstep + (size_t)dx * isx * 3 + c;
+    if (IS > 0) {
+#pragma unroll
+        for (int y = 0; y < IS; y++)
+#pragma unroll
+            for (int x = 0; x < IS; x++) s += p[(size_t)y * sstep + x * 3];
+    } else {
+        for (int y = 0; y < isy; y++)
+            for (int x = 0; x < isx; x++) s += p[(size_t)y * sstep + x * 3];
     }
     const int area = isx * isy;
-    uint8_t* D = dst + ((size_t)dy * dcols + dx) * 3;
-    if (area == 1) {
-        D[0] = (uint8_t)s0, D[1] = (uint8_t)s1, D[2] = (uint8_t)s2;
-    } else if (isx == 2 && isy == 2) {
-        D[0] = (uint8_t)((s0 + 2) >> 2), D[1] = (uint8_t)((s1 + 2) >> 2), D[2] = (uint8_t)((s2 + 2) >> 2);
-    } else {
-        const float f = 1.f / area;
-        D[0] = sat_u8((int)rintf(s0 * f)), D[1] = sat_u8((int)rintf(s1 * f)), D[2] = sat_u8((int)rintf(s2 * f));
-    }
+    uint8_t v;
+    if (area == 1)
+        v = (uint8_t)s;
+    else if (isx == 2 && isy == 2)
+        v = (uint8_t)((s + 2) >> 2);
+    else
+        v = sat_u8((int)rintf(s * (1.f / area)));
+    dst[(size_t)dy * dcols * 3 + e] = v;
 }
 
 // remap(INTER_LINEAR, BORDER_CONSTANT 0) with the fixed-point maps, then RGB2GRAY of the rounded BGR bytes.
@@ -138,22 +209,34 @@ __device__ __forceinline__ int reflect101(int p, int n) {
     return p;
 }
 
-// one block per CLAHE tile: histogram of the (reflect-padded) tile, clip, redistribute, cumulative LUT
-__global__ __launch_bounds__(256) void k_clahe_lut(const uint8_t* __restrict__ gray, int rows, int cols, int tiles_x, int tw, int th,
-                                                    int clip, float lut_scale, uint8_t* __restrict__ lut) {
+// CLAHE tile histograms (of the reflect-padded frame).  64 tiles would leave three quarters of the CUs idle, so every tile
+// is cut into kHistStrips row strips, one block each: LDS histogram, then one global atomic per non-empty bin.
+constexpr int kHistStrips = 8;
+__global__ __launch_bounds__(256) void k_clahe_hist(const uint8_t* __restrict__ gray, int rows, int cols, int tiles_x, int tw, int th,
+                                                     int* __restrict__ hist) {
     __shared__ int s_hist[256];
-    __shared__ int s_scan[256];
-    __shared__ int s_clipped;
-    const int t = threadIdx.x, tx = blockIdx.x % tiles_x, ty = blockIdx.x / tiles_x;
+    const int t = threadIdx.x, tile = blockIdx.x / kHistStrips, strip = blockIdx.x % kHistStrips;
+    const int tx = tile % tiles_x, ty = tile / tiles_x;
+    const int r0 = th * strip / kHistStrips, r1 = th * (strip + 1) / kHistStrips;
     s_hist[t] = 0;
-    if (t == 0) s_clipped = 0;
     __syncthreads();
-    for (int i = t; i < tw * th; i += 256) {
-        const int y = ty * th + i / tw, x = tx * tw + i % tw;
+    for (int i = t; i < tw * (r1 - r0); i += 256) {
+        const int y = ty * th + r0 + i / tw, x = tx * tw + i % tw;
         atomicAdd(&s_hist[gray[(size_t)reflect101(y, rows) * cols + reflect101(x, cols)]], 1);
     }
     __syncthreads();
-    int h = s_hist[t];
+    if (s_hist[t]) atomicAdd(&hist[tile * 256 + t], s_hist[t]);
+}
+
+// one block per tile: clip, redistribute, cumulative LUT; leaves the histogram zeroed for the next frame
+__global__ __launch_bounds__(256) void k_clahe_lut(int* __restrict__ hist, int clip, float lut_scale, uint8_t* __restrict__ lut) {
+    __shared__ int s_scan[256];
+    __shared__ int s_clipped;
+    const int t = threadIdx.x;
+    if (t == 0) s_clipped = 0;
+    int h = hist[blockIdx.x * 256 + t];
+    hist[blockIdx.x * 256 + t] = 0;
+    __syncthreads();
     if (clip > 0) {
         if (h > clip) {
             atomicAdd(&s_clipped, h - clip);
@@ -211,6 +294,7 @@ struct vo_prep {
     vo_prep_params p{};
     bool resize = false, fast = false;
     int isx = 1, isy = 1;
+    int max_taps_x = 0, max_taps_y = 0;  // most taps of one destination index (generic resize)
     int erows = 0, ecols = 0, tw = 0, th = 0, clip = 0;
     float lut_scale = 0.f;
     // device
@@ -220,6 +304,7 @@ struct vo_prep {
     uint8_t* d_gray = nullptr;
     uint8_t* d_out = nullptr;
     uint8_t* d_lut = nullptr;
+    int* d_hist = nullptr;        // [tiles][256], zero between frames
     short2* d_map1 = nullptr;
     uint16_t* d_map2 = nullptr;
     short4* d_wtab = nullptr;
@@ -337,7 +422,7 @@ extern "C" void vo_prep_destroy(vo_prep* pp) {
     hipSetDevice(pp->ctx->device);
     hipStreamSynchronize(pp->ctx->stream);
     if (pp->d_resized && pp->d_resized != pp->d_src) hipFree(pp->d_resized);
-    void* bufs[] = {pp->d_src, pp->d_undist, pp->d_gray, pp->d_out, pp->d_lut, pp->d_map1, pp->d_map2, pp->d_wtab, pp->d_xt, pp->d_yt, pp->d_xo, pp->d_yo};
+    void* bufs[] = {pp->d_src, pp->d_undist, pp->d_gray, pp->d_out, pp->d_lut, pp->d_hist, pp->d_map1, pp->d_map2, pp->d_wtab, pp->d_xt, pp->d_yt, pp->d_xo, pp->d_yo};
     for (void* b : bufs)
         if (b) hipFree(b);
     for (int s = 0; s < kPrepSlots; s++) {
@@ -360,6 +445,8 @@ static int prep_init(vo_prep* pp) {
     VO_HIP(hipMalloc((void**)&pp->d_gray, dst_px));
     VO_HIP(hipMalloc((void**)&pp->d_out, dst_px));
     VO_HIP(hipMalloc((void**)&pp->d_lut, (size_t)p.tiles_x * p.tiles_y * 256));
+    VO_HIP(hipMalloc((void**)&pp->d_hist, (size_t)p.tiles_x * p.tiles_y * 256 * sizeof(int)));
+    VO_HIP(hipMemset(pp->d_hist, 0, (size_t)p.tiles_x * p.tiles_y * 256 * sizeof(int)));
     for (int s = 0; s < kPrepSlots; s++) {
         VO_HIP(hipHostMalloc((void**)&pp->h_stage[s], src_bytes, hipHostMallocDefault));
         VO_HIP(hipEventCreateWithFlags(&pp->ev[s], hipEventDisableTiming));
@@ -370,6 +457,17 @@ static int prep_init(vo_prep* pp) {
         std::vector<int> xo, yo;
         area_taps(p.src_cols, p.dst_cols, (double)p.src_cols / p.dst_cols, xt, xo);
         area_taps(p.src_rows, p.dst_rows, (double)p.src_rows / p.dst_rows, yt, yo);
+        auto most = [](const std::vector<AreaTap>& t, const std::vector<int>& o) {
+            int m = 0;
+            bool consecutive = true;
+            for (size_t d = 0; d + 1 < o.size(); d++) {
+                m = std::max(m, o[d + 1] - o[d]);
+                for (int k = o[d] + 1; k < o[d + 1]; k++) consecutive &= t[k].si == t[k - 1].si + 1;
+            }
+            return consecutive ? m : 1 << 20;  // non-consecutive taps (never for a shrink) -> the any-scale kernel
+        };
+        pp->max_taps_x = most(xt, xo);
+        pp->max_taps_y = most(yt, yo);
         VO_TRY(upload_vec(&pp->d_xt, xt.data(), xt.size() * sizeof(AreaTap)));
         VO_TRY(upload_vec(&pp->d_yt, yt.data(), yt.size() * sizeof(AreaTap)));
         VO_TRY(upload_vec(&pp->d_xo, xo.data(), xo.size() * sizeof(int)));
@@ -423,6 +521,8 @@ extern "C" int vo_prep_create(vo_ctx* ctx, const vo_prep_params* p, vo_prep** ou
     return VO_OK;
 }
 
+static int prep_passes(vo_prep* pp, uint8_t* d_dst, int dst_step);
+
 // upload one frame through the pinned staging slots and run the four passes; result to (d_dst, dst_step) on the device
 static int prep_enqueue(vo_prep* pp, const uint8_t* bgr, size_t step, uint8_t* d_dst, int dst_step) {
     vo_ctx* ctx = pp->ctx;
@@ -441,14 +541,56 @@ static int prep_enqueue(vo_prep* pp, const uint8_t* bgr, size_t step, uint8_t* d
     VO_HIP(hipMemcpyAsync(pp->d_src, pp->h_stage[s], row_bytes * p.src_rows, hipMemcpyHostToDevice, ctx->stream));
     VO_HIP(hipEventRecord(pp->ev[s], ctx->stream));
     pp->pending[s] = true;
+    return prep_passes(pp, d_dst, dst_step);
+}
+
+// the four passes on the frame resident in d_src
+static int prep_passes(vo_prep* pp, uint8_t* d_dst, int dst_step) {
+    vo_ctx* ctx = pp->ctx;
+    const vo_prep_params& p = pp->p;
+    const size_t row_bytes = (size_t)p.src_cols * 3;
     const int R = p.dst_rows, C = p.dst_cols;
     if (pp->resize) {
         StageScope sc(ctx, ST_PREP_RESIZE);
-        const dim3 grid((C + 255) / 256, R);
-        if (pp->fast)
-            k_resize_area_int<<<grid, 256, 0, ctx->stream>>>(pp->d_src, (int)row_bytes, pp->isx, pp->isy, pp->d_resized, R, C);
-        else
-            k_resize_area<<<grid, 256, 0, ctx->stream>>>(pp->d_src, (int)row_bytes, pp->d_xt, pp->d_xo, pp->d_yt, pp->d_yo, pp->d_resized, R, C);
+        const dim3 grid((C * 3 + 255) / 256, R);
+        const int sb = (int)row_bytes;
+        if (pp->fast) {
+            auto k = k_resize_area_int<0>;
+            if (pp->isx == pp->isy && pp->isx >= 2 && pp->isx <= 4)
+                k = pp->isx == 2 ? k_resize_area_int<2> : pp->isx == 3 ? k_resize_area_int<3> : k_resize_area_int<4>;
+            k<<<grid, 256, 0, ctx->stream>>>(pp->d_src, sb, pp->isx, pp->isy, pp->d_resized, R, C);
+        } else {
+            auto k = k_resize_area;
+            const int mx = pp->max_taps_x <= 4 ? 4 : pp->max_taps_x <= 6 ? 6 : 8, my = pp->max_taps_y <= 4 ? 4 : pp->max_taps_y <= 6 ? 6 : 8;
+            // staged form: 86 destination pixels of at most 7 source columns each fit one LDS row
+            const bool lds = sb % 16 == 0 && pp->max_taps_y <= 8 && pp->max_taps_x <= 8 && (double)p.src_cols / p.dst_cols <= 7.0;
+            if (lds) {
+                switch (mx * 10 + my) {
+                    case 44: k = k_resize_area_lds<4, 4>; break;
+                    case 46: k = k_resize_area_lds<4, 6>; break;
+                    case 48: k = k_resize_area_lds<4, 8>; break;
+                    case 64: k = k_resize_area_lds<6, 4>; break;
+                    case 66: k = k_resize_area_lds<6, 6>; break;
+                    case 68: k = k_resize_area_lds<6, 8>; break;
+                    case 84: k = k_resize_area_lds<8, 4>; break;
+                    case 86: k = k_resize_area_lds<8, 6>; break;
+                    default: k = k_resize_area_lds<8, 8>; break;
+                }
+            } else if (pp->max_taps_x <= 8 && pp->max_taps_y <= 8) {
+                switch (mx * 10 + my) {
+                    case 44: k = k_resize_area_u<4, 4>; break;
+                    case 46: k = k_resize_area_u<4, 6>; break;
+                    case 48: k = k_resize_area_u<4, 8>; break;
+                    case 64: k = k_resize_area_u<6, 4>; break;
+                    case 66: k = k_resize_area_u<6, 6>; break;
+                    case 68: k = k_resize_area_u<6, 8>; break;
+                    case 84: k = k_resize_area_u<8, 4>; break;
+                    case 86: k = k_resize_area_u<8, 6>; break;
+                    default: k = k_resize_area_u<8, 8>; break;
+                }
+            }
+            k<<<grid, 256, 0, ctx->stream>>>(pp->d_src, sb, pp->d_xt, pp->d_xo, pp->d_yt, pp->d_yo, pp->d_resized, R, C);
+        }
     }
     {
         StageScope sc(ctx, ST_PREP_REMAP);
@@ -456,7 +598,8 @@ static int prep_enqueue(vo_prep* pp, const uint8_t* bgr, size_t step, uint8_t* d
     }
     {
         StageScope sc(ctx, ST_PREP_CLAHE);
-        k_clahe_lut<<<p.tiles_x * p.tiles_y, 256, 0, ctx->stream>>>(pp->d_gray, R, C, p.tiles_x, pp->tw, pp->th, pp->clip, pp->lut_scale, pp->d_lut);
+        k_clahe_hist<<<p.tiles_x * p.tiles_y * kHistStrips, 256, 0, ctx->stream>>>(pp->d_gray, R, C, p.tiles_x, pp->tw, pp->th, pp->d_hist);
+        k_clahe_lut<<<p.tiles_x * p.tiles_y, 256, 0, ctx->stream>>>(pp->d_hist, pp->clip, pp->lut_scale, pp->d_lut);
         k_clahe_apply<<<dim3((C + 255) / 256, R), 256, 0, ctx->stream>>>(pp->d_gray, R, C, p.tiles_x, p.tiles_y, 1.0f / pp->tw, 1.0f / pp->th,
                                                                           pp->d_lut, d_dst, dst_step);
     }
@@ -483,6 +626,13 @@ extern "C" int vo_prep_to_batch(vo_prep* pp, const uint8_t* bgr, size_t step, vo
     VO_HIP(hipSetDevice(pp->ctx->device));
     // same stream as the batch's pipeline: the frame is in place before vo_batch_run's kernels start
     return prep_enqueue(pp, bgr, step, b->fs.img + (size_t)frame * b->fs.img_stride(), b->cols);
+}
+
+extern "C" int vo_prep_rerun(vo_prep* pp, int reps) {
+    if (!pp || reps < 0) return VO_ERR_INVALID_ARG;
+    VO_HIP(hipSetDevice(pp->ctx->device));
+    for (int r = 0; r < reps; r++) VO_TRY(prep_passes(pp, pp->d_out, pp->p.dst_cols));
+    return VO_OK;
 }
 
 extern "C" int vo_prep_fetch(vo_prep* pp, int what, void* dst, size_t bytes) {
