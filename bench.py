@@ -144,6 +144,10 @@ def main():
     batch.sync()
     prof = ctx.profile()
     ctx.profile_enable(False)
+    import ctypes as C
+
+    redo = C.c_int32(-1)  # queries of the last step whose matcher shortlist was not certified (exact scan instead)
+    ctx._chk(ctx.lib.vo_debug_fetch(ctx._h, 4, C.byref(redo), C.c_size_t(4)))
 
     if rank == 0:
         assert rec_all.shape[0] == args.batch * world
@@ -255,6 +259,7 @@ def main():
             "roofline_all": roofline_all,
             "cpu_baseline": cpu,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
+            "match_exact_scans_per_step": redo.value,
         }
         print(json.dumps(line))
     batch.close()

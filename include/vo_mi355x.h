@@ -210,11 +210,15 @@ int vo_seq_set_frame(vo_batch* b, int frame, const uint8_t* img, size_t step);
 int vo_seq_set_pair(vo_batch* b, int pair, int frame_a, int frame_b, const double K[9]);
 
 /* Inspection of the context's last single-call RANSAC (tests): what = 0 tuples [4096][5] int32,
- * 1 nmodels [4096] int32, 2 counts [4096][10] int32, 3 models [4096][10][9] double.              */
+ * 1 nmodels [4096] int32, 2 counts [4096][10] int32, 3 models [4096][10][9] double;
+ * what = 4: one int32, the queries of the context's last matcher launch whose MFMA shortlist could not be
+ * certified and that took the exact scan instead.                                                 */
 int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes);
 /* Test hook, no counterpart in the reference.  key 0: value != 0 sends EVERY keypoint's descriptor window
  * through the sequential coordinate walk (the path otherwise taken only when the closed-form window
- * coordinates are not exactly representable); results are identical either way.                         */
+ * coordinates are not exactly representable); results are identical either way.
+ * key 1: value != 0 certifies no matcher shortlist, so that EVERY query takes the exact scan of all train rows
+ * (otherwise a handful per frame pair); results are identical either way.                                */
 int vo_debug_set(vo_ctx* ctx, int key, int value);
 
 /* ---- N1: gates and pose chain of the node, host arithmetic only (no GPU, no context) ----------------

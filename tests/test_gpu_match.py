@@ -31,6 +31,64 @@ def test_knn2_exact_ties_go_to_lower_index(ctx):
     assert np.all(idx[:50, 0] == np.arange(50)) and np.all(idx[:50, 1] == np.arange(50) + 50)
 
 
+def _redo_count(ctx):
+    import ctypes as C
+
+    n = C.c_int32(-1)
+    ctx._chk(ctx.lib.vo_debug_fetch(ctx._h, 4, C.byref(n), C.c_size_t(4)))
+    return n.value
+
+
+def test_knn2_exact_scan_path_gives_the_same_answer(ctx):
+    """vo_debug_set key 1 certifies no shortlist: every query goes through k_match_exact."""
+    a = synth.surf_like_descriptors(700, 31)
+    b = synth.surf_like_descriptors(900, 32)
+    b[:100] = a[:100]
+    ridx, rdist = O.match_knn2(a, b)
+    idx, dist = ctx.match_knn2(a, b)
+    few = _redo_count(ctx)
+    ctx.debug_set(1, 1)
+    try:
+        idx2, dist2 = ctx.match_knn2(a, b)
+        every = _redo_count(ctx)
+    finally:
+        ctx.debug_set(1, 0)
+    assert every == 700 and few < 70
+    for i, d in ((idx, dist), (idx2, dist2)):
+        assert np.array_equal(i, ridx) and np.array_equal(d.view(np.uint32), rdist.view(np.uint32))
+
+
+def test_knn2_crowded_neighbourhoods_fall_back_to_the_exact_scan(ctx):
+    """Many train rows within 1e-5 of the second-best distance: the split-bf16 scores cannot order them, the certificate
+    must notice and the exact scan must reproduce the oracle's order, including exact ties (lower index first)."""
+    rng = np.random.default_rng(41)
+    a = synth.surf_like_descriptors(256, 41)
+    base = synth.surf_like_descriptors(2048, 42)
+    b = base.copy()
+    for q in range(0, 256, 4):  # a cluster of 12 near-copies of one train row per chosen query, spread over the tiles
+        centre = a[q] + rng.normal(0, 0.02, 64).astype(np.float32)
+        rows = rng.choice(2048, 12, replace=False)
+        b[rows] = centre + rng.normal(0, 2e-6, (12, 64)).astype(np.float32)
+        b[rows[:3]] = b[rows[3]]  # and exact duplicates among them
+    idx, dist = ctx.match_knn2(a, b)
+    n_redo = _redo_count(ctx)
+    ridx, rdist = O.match_knn2(a, b)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+    assert n_redo >= 5, n_redo  # groups holding more than four of a cluster were noticed (12 rows over 8 groups)
+
+
+def test_knn2_unnormalised_descriptors(ctx):
+    """The certificate's margin scales with the operands' norms."""
+    rng = np.random.default_rng(51)
+    a = (synth.surf_like_descriptors(300, 51) * rng.uniform(0.5, 30.0, (300, 1))).astype(np.float32)
+    b = (synth.surf_like_descriptors(1500, 52) * rng.uniform(0.5, 30.0, (1500, 1))).astype(np.float32)
+    idx, dist = ctx.match_knn2(a, b)
+    ridx, rdist = O.match_knn2(a, b)
+    assert np.array_equal(idx, ridx)
+    assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+
+
 def test_knn2_against_numpy(ctx):
     a = synth.surf_like_descriptors(500, 21)
     b = synth.surf_like_descriptors(700, 22)

@@ -149,6 +149,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.desc, (size_t)F * cap * 64));
     VO_TRY(dalloc(fs.descT, (size_t)F * cap * 64));
     VO_TRY(dalloc(fs.nrm, (size_t)F * cap));
+    VO_TRY(dalloc(fs.nmax, (size_t)F));
     VO_TRY(dalloc(fs.cnt, (size_t)F));
     VO_TRY(dalloc(fs.cls_list, (size_t)5 * F * cap));
     VO_TRY(dalloc(fs.cls_cnt, (size_t)kClsCntInts));
@@ -169,6 +170,7 @@ void vo_frameset_free(FrameSet& fs) {
     dfree(fs.desc);
     dfree(fs.descT);
     dfree(fs.nrm);
+    dfree(fs.nmax);
     dfree(fs.cnt);
     dfree(fs.cls_list);
     dfree(fs.cls_cnt);
@@ -337,6 +339,8 @@ int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp)
     const size_t pk = (size_t)P * kp_cap, pm = (size_t)P * match_cap, ph = (size_t)P * max_hyp;
     VO_TRY(dalloc(ps.cand_val, pk * 32));
     VO_TRY(dalloc(ps.cand_idx, pk * 32));
+    VO_TRY(dalloc(ps.redo_list, pk));
+    VO_TRY(dalloc(ps.redo_cnt, (size_t)1));
     VO_TRY(dalloc(ps.knn_idx, pk * 2));
     VO_TRY(dalloc(ps.knn_dist, pk * 2));
     VO_TRY(dalloc(ps.p1, pm * 2));
@@ -371,6 +375,8 @@ void vo_pairset_free(PairSet& ps) {
     dfree(ps.frames);
     dfree(ps.cand_val);
     dfree(ps.cand_idx);
+    dfree(ps.redo_list);
+    dfree(ps.redo_cnt);
     dfree(ps.knn_idx);
     dfree(ps.knn_dist);
     dfree(ps.p1);
@@ -896,7 +902,15 @@ extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2
 // what: 0 = tuples [max_hyp][5] int32, 1 = nmodels [max_hyp] int32, 2 = counts [max_hyp][10] int32,
 //       3 = models [max_hyp][10][9] double.  Copies min(bytes, size) bytes of pair 0 of the context's scratch set.
 extern "C" int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes) {
-    if (!ctx || !dst || !ctx->ps.st) return VO_ERR_INVALID_ARG;
+    if (!ctx || !dst) return VO_ERR_INVALID_ARG;
+    if (what == 4) {  // queries of the last matcher launch (any batch of this context) that took the exact scan
+        if (!ctx->last_redo_cnt || bytes < sizeof(int)) return VO_ERR_INVALID_ARG;
+        VO_HIP(hipSetDevice(ctx->device));
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+        VO_HIP(hipMemcpy(dst, ctx->last_redo_cnt, sizeof(int), hipMemcpyDeviceToHost));
+        return VO_OK;
+    }
+    if (!ctx->ps.st) return VO_ERR_INVALID_ARG;
     const PairSet& ps = ctx->ps;
     const void* src = nullptr;
     size_t size = 0;
@@ -916,6 +930,7 @@ extern "C" int vo_debug_set(vo_ctx* ctx, int key, int value) {
     if (!ctx) return VO_ERR_INVALID_ARG;
     switch (key) {
         case 0: ctx->force_seq_describe = value ? 1 : 0; return VO_OK;
+        case 1: ctx->force_exact_match = value ? 1 : 0; return VO_OK;
         default: return VO_ERR_INVALID_ARG;
     }
 }

@@ -133,8 +133,9 @@ struct FrameSet {
     vo_keypoint* kp = nullptr;      // [F][cap] sorted
     int* rank = nullptr;            // [F][cap]
     float* desc = nullptr;          // [F][cap][64]
-    float* descT = nullptr;         // [F][cap/32][8][64][4] MFMA operand layout + norms
+    float* descT = nullptr;         // [F][cap/32][8][64] x 16 B: MFMA operand layout (bf16 high parts, bf16 low parts)
     float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
+    int* nmax = nullptr;            // [F] bits of the largest ||b||^2 of the frame
     FrameCounters* cnt = nullptr;   // [F]
     int* cls_list = nullptr;        // [5][F*cap] keypoints (frame*cap + k) of each descriptor window class; list 4 = sequential-walk fallback
     int* cls_cnt = nullptr;         // [kClsCntInts] list lengths [0..4]; work-queue tickets [8 + 8*cls + segment]
@@ -148,9 +149,11 @@ struct PairSet {
     int P = 0, kp_cap = 0, match_cap = 0, max_hyp = 0;
     int n_split = 0;            // train-range splits of the MFMA pass
     int2* frames = nullptr;     // [P] (query frame, train frame) of every pair; default (2p, 2p+1)
-    float* cand_val = nullptr;  // [P][kp_cap][n_split*4]
+    float* cand_val = nullptr;  // [P][kp_cap][32] shortlist scores (4 per group = lane half x train split)
     int* cand_idx = nullptr;
     int* knn_idx = nullptr;     // [P][kp_cap][2]
+    int* redo_list = nullptr;   // [P*kp_cap] queries whose shortlist could not be certified (pair*cap + q)
+    int* redo_cnt = nullptr;    // [1]
     float* knn_dist = nullptr;  // [P][kp_cap][2]
     float* p1 = nullptr;        // [P][match_cap][2]
     float* p2 = nullptr;
@@ -180,6 +183,8 @@ struct vo_ctx {
     uint32_t* d_rng_raw = nullptr;  // unused placeholder (rng stream is generated on device)
     bool profiling = false;
     int force_seq_describe = 0;     // vo_debug_set key 0
+    int force_exact_match = 0;      // vo_debug_set key 1: no shortlist is certified, every query takes the exact scan
+    const int* last_redo_cnt = nullptr;  // device counter of the last matcher launch (vo_debug_fetch 4)
     StageTimer timers[ST_COUNT];
     // lazily sized scratch for the single-call entry points
     FrameSet fs;

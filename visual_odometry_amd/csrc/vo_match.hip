@@ -5,13 +5,18 @@
 // reference's FLANN matcher is replaced by the exact brute-force search of its "OLD METHOD"
 // comment, :752-755, as the north star asks).
 //
-//   k_match_prep   : train descriptors -> MFMA operand layout, plus -0.5*||b||^2
-//   k_match_mfma   : dense contraction a.b - 0.5||b||^2 on v_mfma_f32_32x32x2_f32 with queries on
-//                    the lanes (columns) and train rows in the accumulator registers, so the
-//                    running top-2 per query is pure in-lane VALU work; the train range is split
-//                    8 ways over wavefronts, each keeps a top-2 per lane half -> 32 candidates
-//   k_match_select : exact re-scoring of the candidates with the oracle's sequential
-//                    sum (a-b)^2, 32-lane (dist, index) min-reductions -> knn[2]
+//   k_match_prep   : train descriptors -> MFMA operand layout (bf16 high / low parts), -0.5*||b||^2, max ||b||^2
+//   k_match_bf3    : dense contraction a.b - 0.5||b||^2 on v_mfma_f32_32x32x16_bf16 with each float split into two bf16
+//                    (a = ah + al): ah.bh + ah.bl + al.bh, 12 MFMAs of 32 cycles per 32 x 32 tile instead of 32 FP32
+//                    MFMAs of 64 cycles, error <= 3 * 2^-18 |a||b|.  Queries on the lanes (columns), train rows in the
+//                    accumulator registers, so the shortlist (the three best 4-row blocks per group and a bound on the
+//                    rest) is in-lane VALU work: max, med3, compare + branch per block, insertion only on a hit
+//   k_match_select : exact re-scoring of the candidates with the oracle's sequential sum (a-b)^2, (dist, index)
+//                    min-reductions -> knn[2]; CERTIFIES the shortlist: every train row left out of a group scored no
+//                    better than the group's bound t4, so if ||a||^2 - 2*t4 exceeds the second-best exact
+//                    distance by more than the error bound for every group, no left-out row can be a neighbour.
+//                    Queries that fail the test go to a list
+//   k_match_exact  : exact scan of all train rows for the listed queries (a handful per frame pair)
 //   k_match_filter : d0 < 0.7 d1 and ROI on keypoint 1, ordered ballot compaction, point gather
 // The MFMA value is only used to shortlist; the distances that reach the ratio test are exact.
 #include <cfloat>
@@ -20,12 +25,37 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-constexpr int kSplit = 8;            // train-range splits
-constexpr int kCand = 4 * kSplit;    // candidates per query (top-2 per lane half per split)
 
 // ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t bf16_rne(float f) {  // round to nearest even, finite inputs
+    const uint32_t u = __float_as_uint(f);
+    return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
+}
+// a = hi + lo + r with hi, lo bf16 and |r| <= 2^-18 |a|
+__device__ __forceinline__ void bf16_split(float a, uint32_t& hi, uint32_t& lo) {
+    hi = bf16_rne(a);
+    lo = bf16_rne(a - __uint_as_float(hi << 16));  // the subtraction is exact
+}
+// eight consecutive floats -> their high parts and low parts, packed for one MFMA operand (element j in half-word j)
+__device__ __forceinline__ void bf16_split8(const float4& v0, const float4& v1, uint4& hi, uint4& lo) {
+    uint32_t h[8], l[8];
+    bf16_split(v0.x, h[0], l[0]);
+    bf16_split(v0.y, h[1], l[1]);
+    bf16_split(v0.z, h[2], l[2]);
+    bf16_split(v0.w, h[3], l[3]);
+    bf16_split(v1.x, h[4], l[4]);
+    bf16_split(v1.y, h[5], l[5]);
+    bf16_split(v1.z, h[6], l[6]);
+    bf16_split(v1.w, h[7], l[7]);
+    hi = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+}
+
+// Operand layout of a 32-row tile: 8 slabs of 64 lanes x 16 bytes.  Lane (h, r) of slab m (0..3) holds the high parts of
+// row r, elements 32h + 8m .. + 7; slab 4 + m the low parts.
 __global__ __launch_bounds__(64) void k_match_prep(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt,
-                                                   int cap, float4* __restrict__ descT_base, float* __restrict__ nrm_base) {
+                                                   int cap, float4* __restrict__ descT_base, float* __restrict__ nrm_base,
+                                                   int* __restrict__ nmax_bits) {
     const int frame = blockIdx.y, tile = blockIdx.x;
     const int n = min(cnt[frame].n_raw, cap);
     if (tile * 32 >= n) return;
@@ -34,144 +64,189 @@ __global__ __launch_bounds__(64) void k_match_prep(const float* __restrict__ des
     const float4* row = reinterpret_cast<const float4*>(desc_base + ((size_t)frame * cap + r) * 64);
     float4* out = descT_base + ((size_t)frame * (cap / 32) + tile) * 8 * 64;
     float ss = 0.f;
+    float4 v[8];
 #pragma unroll
     for (int s4 = 0; s4 < 8; s4++) {
-        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (r < n) v = row[8 * h + s4];
-        out[s4 * 64 + lane] = v;
-        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+        v[s4] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < n) v[s4] = row[8 * h + s4];
+        ss += v[s4].x * v[s4].x + v[s4].y * v[s4].y + v[s4].z * v[s4].z + v[s4].w * v[s4].w;
+    }
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        uint4 hi, lo;
+        bf16_split8(v[2 * m], v[2 * m + 1], hi, lo);
+        reinterpret_cast<uint4*>(out)[m * 64 + lane] = hi;
+        reinterpret_cast<uint4*>(out)[(4 + m) * 64 + lane] = lo;
     }
     ss += __shfl_xor(ss, 32, 64);
     if (h == 0) nrm_base[(size_t)frame * cap + r] = (r < n) ? -0.5f * ss : -1e30f;
+    // largest squared norm of the frame (non-negative floats order like their bit patterns): scales the certificate's margin
+    float mx = (r < n) ? ss : 0.f;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) mx = fmaxf(mx, __shfl_xor(mx, m, 64));
+    if (lane == 0) atomicMax(&nmax_bits[frame], __float_as_int(mx));
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void top2_update(float v, int idx, float& v1, int& i1, float& v2, int& i2) {
-    const bool g1 = v > v1, g2 = v > v2;
-    v2 = g1 ? v1 : (g2 ? v : v2);
-    i2 = g1 ? i1 : (g2 ? idx : i2);
-    v1 = g1 ? v : v1;
-    i1 = g1 ? idx : i1;
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+union Bf16Frag {
+    uint4 u;
+    bf16x8 v;
+};
+
+// Shortlist bookkeeping.  A lane sees 16 scores per tile: 4 BLOCKS of 4 consecutive train rows (accumulator registers
+// 4j .. 4j+3 = tile rows 8j + 4h ..+3).  Per group (lane half x train split) it keeps the three blocks with the largest
+// maximum, and t4 = the largest maximum among all other blocks.  The two best rows of the group always lie in its two best
+// blocks (the runner-up row is either in the winner's block or is the maximum of its own block), so the rows of the kept
+// blocks are a complete shortlist as far as the scores can be trusted, and t4 bounds every row that was left out.
+// Cost per block: v_max3 + v_max, one v_med3 (t4 = med3(m, b3, t4) is "max of everything not kept" without a branch) and
+// one compare + branch; the 13-instruction insertion runs only when some lane's block beats its third best.
+__device__ __forceinline__ void top3_insert(float m, int id, float (&bv)[3], int (&bi)[3]) {
+    const bool g0 = m > bv[0], g1 = m > bv[1], g2 = m > bv[2];
+    bv[2] = g1 ? bv[1] : (g2 ? m : bv[2]);
+    bi[2] = g1 ? bi[1] : (g2 ? id : bi[2]);
+    bv[1] = g0 ? bv[0] : (g1 ? m : bv[1]);
+    bi[1] = g0 ? bi[0] : (g1 ? id : bi[1]);
+    bv[0] = g0 ? m : bv[0];
+    bi[0] = g0 ? id : bi[0];
 }
 
+__device__ __forceinline__ float max4(float a, float b, float c, float d) {  // finite inputs: no NaN canonicalisation wanted
+    float m;
+    asm("v_max3_f32 %0, %1, %2, %3" : "=v"(m) : "v"(a), "v"(b), "v"(c));
+    asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(m), "v"(d));
+    return m;
+}
+
+constexpr int kKeep = 3;         // blocks kept per group
+constexpr int kCandStride = 32;  // slots per query in cand_val / cand_idx: 8 groups x (3 block ids | t4)
+
 template <int NC>  // 32-query blocks per wavefront
-__global__ __launch_bounds__(256) void k_match_mfma(const float* __restrict__ desc_base,
-                                                    const float4* __restrict__ descT_base,
-                                                    const float* __restrict__ nrm_base,
-                                                    const FrameCounters* __restrict__ cnt, int cap,
-                                                    const int2* __restrict__ pair_frames,
-                                                    float* __restrict__ cand_val, int* __restrict__ cand_idx) {
-    const int pair = blockIdx.y;
+__global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ desc_base, const uint4* __restrict__ descT_base,
+                                                   const float* __restrict__ nrm_base, const FrameCounters* __restrict__ cnt, int cap,
+                                                   const int2* __restrict__ pair_frames, int ksplit, int bpp, int xcd_map,
+                                                   float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    // Workgroups are dealt to the 8 XCDs round robin (linear id % 8).  All workgroups of a pair scan the same 2 MB of train
+    // operands, so a pair is kept on ONE XCD (pair = xcd + 8 * ...): its L2 then streams two pairs at a time instead of
+    // every pair in flight, and HBM delivers each operand tile once.
+    int pair, bx;
+    if (xcd_map) {
+        const int lin = blockIdx.x, xcd = lin & 7, k = lin >> 3;
+        pair = xcd + 8 * (k / bpp);
+        bx = k - (k / bpp) * bpp;
+    } else {
+        pair = blockIdx.x / bpp;
+        bx = blockIdx.x - pair * bpp;
+    }
     const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
     const int nA = min(cnt[fa].n_raw, cap), nB = min(cnt[fb].n_raw, cap);
     const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
-    const int w = blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int qb = w / kSplit, sp = w - qb * kSplit;
+    const int w = bx * 4 + (threadIdx.x >> 6);
+    const int qb = w / ksplit, sp = w - qb * ksplit;
     const int q0 = qb * 32 * NC;
     if (q0 >= nA) return;
     const int ntiles = (nB + 31) >> 5;
 
-    // query operands: lane holds query[q0 + 32c + l31][32h + s], s = 0..31 (k is permuted
-    // identically on both operands: lane half h covers k in [32h, 32h+32))
-    float bq[NC][32];
+    // query operands: the lane's query row, elements 32h + 8m .. + 7 for MFMA m (the same k permutation as the train side)
+    Bf16Frag qh[NC][4], ql[NC][4];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int row = q0 + 32 * c + l31;
         const float4* p = reinterpret_cast<const float4*>(desc_base + ((size_t)fa * cap + row) * 64 + 32 * h);
 #pragma unroll
-        for (int s4 = 0; s4 < 8; s4++) {
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < nA) v = p[s4];
-            bq[c][4 * s4 + 0] = v.x;
-            bq[c][4 * s4 + 1] = v.y;
-            bq[c][4 * s4 + 2] = v.z;
-            bq[c][4 * s4 + 3] = v.w;
+        for (int m = 0; m < 4; m++) {
+            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+            if (row < nA) {
+                v0 = p[2 * m];
+                v1 = p[2 * m + 1];
+            }
+            bf16_split8(v0, v1, qh[c][m].u, ql[c][m].u);
         }
     }
-    float v1[NC], v2[NC];
-    int i1[NC], i2[NC];
+    float bv[NC][kKeep], t4[NC];
+    int bi[NC][kKeep];
 #pragma unroll
     for (int c = 0; c < NC; c++) {
-        v1[c] = v2[c] = -FLT_MAX;
-        i1[c] = i2[c] = -1;
+        t4[c] = -FLT_MAX;
+#pragma unroll
+        for (int k = 0; k < kKeep; k++) {
+            bv[c][k] = -FLT_MAX;
+            bi[c][k] = -1;
+        }
     }
-    const float4* __restrict__ descT = descT_base + (size_t)fb * (cap / 32) * 8 * 64;
+    const uint4* __restrict__ descT = descT_base + (size_t)fb * (cap / 32) * 8 * 64;
     const float* __restrict__ nrm = nrm_base + (size_t)fb * cap;
 
-    // Operands of a tile come in two halves of four float4 per lane; each half is re-loaded for the NEXT tile right after
-    // its MFMAs were issued, so the loads fly under the other half's MFMAs and the top-2 update (register budget:
-    // 2 x 16 operand registers instead of 32 + 32 for a whole-tile double buffer).
-    float4 ha[4], hb[4];
-    float an_next = 0.f;
+    // operands of the NEXT tile are re-loaded slab by slab right after the MFMAs that used the slab were issued
+    Bf16Frag th[4], tl[4];
+    float4 n4[4];
     if (sp < ntiles) {
-        const float4* tp = descT + (size_t)sp * 8 * 64 + lane;
+        const uint4* tp = descT + (size_t)sp * 8 * 64 + lane;
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) {
-            ha[s4] = tp[s4 * 64];
-            hb[s4] = tp[(s4 + 4) * 64];
+        for (int m = 0; m < 4; m++) {
+            th[m].u = tp[m * 64];
+            tl[m].u = tp[(4 + m) * 64];
         }
-        an_next = (h == 0) ? nrm[sp * 32 + l31] : 0.f;
+        // -0.5||b||^2 of the lane's 16 accumulator rows: register 4j + e is tile row 8j + 4h + e
+#pragma unroll
+        for (int j = 0; j < 4; j++) n4[j] = *reinterpret_cast<const float4*>(nrm + sp * 32 + 8 * j + 4 * h);
     }
-    for (int t = sp; t < ntiles; t += kSplit) {
-        const float an = an_next;
-        const bool more = t + kSplit < ntiles;
-        const float4* tn = descT + (size_t)(more ? t + kSplit : t) * 8 * 64 + lane;
+    for (int t = sp; t < ntiles; t += ksplit) {
+        const bool more = t + ksplit < ntiles;
+        const int tn_i = more ? t + ksplit : t;
+        const uint4* tn = descT + (size_t)tn_i * 8 * 64 + lane;
         f32x16 acc[NC];
 #pragma unroll
         for (int c = 0; c < NC; c++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) acc[c][r] = 0.f;
-#define VO_MFMA4(A, S4)                                                                                       \
-    _Pragma("unroll") for (int c = 0; c < NC; c++)                                                            \
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.x, bq[c][4 * (S4) + 0], acc[c], 0, 0, 0);             \
-    _Pragma("unroll") for (int c = 0; c < NC; c++)                                                            \
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.y, bq[c][4 * (S4) + 1], acc[c], 0, 0, 0);             \
-    _Pragma("unroll") for (int c = 0; c < NC; c++)                                                            \
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.z, bq[c][4 * (S4) + 2], acc[c], 0, 0, 0);             \
-    _Pragma("unroll") for (int c = 0; c < NC; c++)                                                            \
-        acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(A.w, bq[c][4 * (S4) + 3], acc[c], 0, 0, 0);
+            for (int j = 0; j < 4; j++) {
+                acc[c][4 * j + 0] = n4[j].x;
+                acc[c][4 * j + 1] = n4[j].y;
+                acc[c][4 * j + 2] = n4[j].z;
+                acc[c][4 * j + 3] = n4[j].w;
+            }
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) { VO_MFMA4(ha[s4], s4) }
+        for (int j = 0; j < 4; j++) n4[j] = *reinterpret_cast<const float4*>(nrm + tn_i * 32 + 8 * j + 4 * h);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) ha[s4] = tn[s4 * 64];
+        for (int m = 0; m < 4; m++) {
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) { VO_MFMA4(hb[s4], s4 + 4) }
+            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[m].v, qh[c][m].v, acc[c], 0, 0, 0);
 #pragma unroll
-        for (int s4 = 0; s4 < 4; s4++) hb[s4] = tn[(s4 + 4) * 64];
-#undef VO_MFMA4
-        an_next = (h == 0) ? nrm[(more ? t + kSplit : t) * 32 + l31] : 0.f;
-        // one more k-step adds -0.5*||b_i||^2 to every column of row i
+            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[m].v, ql[c][m].v, acc[c], 0, 0, 0);
+            th[m].u = tn[m * 64];
 #pragma unroll
-        for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(an, 1.0f, acc[c], 0, 0, 0);
-        // accumulator register r of lane (h, l31) is train row (r&3) + 8*(r>>2) + 4h of the tile
-        const int ibase = t * 32 + 4 * h;
+            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[m].v, qh[c][m].v, acc[c], 0, 0, 0);
+            tl[m].u = tn[(4 + m) * 64];
+        }
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int idx = ibase + (r & 3) + 8 * (r >> 2);
+        for (int j = 0; j < 4; j++) {
 #pragma unroll
-            for (int c = 0; c < NC; c++) top2_update(acc[c][r], idx, v1[c], i1[c], v2[c], i2[c]);
+            for (int c = 0; c < NC; c++) {
+                const float m = max4(acc[c][4 * j], acc[c][4 * j + 1], acc[c][4 * j + 2], acc[c][4 * j + 3]);
+                t4[c] = __builtin_amdgcn_fmed3f(m, bv[c][kKeep - 1], t4[c]);
+                if (__any(m > bv[c][kKeep - 1])) top3_insert(m, 4 * t + j, bv[c], bi[c]);  // rare after the first tiles
+            }
         }
     }
 #pragma unroll
     for (int c = 0; c < NC; c++) {
         const int row = q0 + 32 * c + l31;
         if (row < nA) {
-            const size_t o = ((size_t)pair * cap + row) * kCand + sp * 4 + 2 * h;
-            // entries whose value never left the sentinel (padding rows) are not candidates
-            cand_idx[o] = (v1[c] > -1e29f) ? i1[c] : -1;
-            cand_idx[o + 1] = (v2[c] > -1e29f) ? i2[c] : -1;
-            cand_val[o] = v1[c];
-            cand_val[o + 1] = v2[c];
+            const size_t o = ((size_t)pair * cap + row) * kCandStride + (sp * 2 + h) * 4;
+#pragma unroll
+            for (int k = 0; k < kKeep; k++) cand_idx[o + k] = (bv[c][k] > -1e29f) ? bi[c][k] : -1;  // sentinel / all-padding blocks
+            cand_val[o + 3] = t4[c];
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ void min_pair32(float& d, int& i) {
+template <int W>
+__device__ __forceinline__ void min_pair(float& d, int& i) {  // (distance, index) minimum over W consecutive lanes
 #pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) {
-        const float od = __shfl_xor(d, m, 32);
-        const int oi = __shfl_xor(i, m, 32);
+    for (int m = W / 2; m >= 1; m >>= 1) {
+        const float od = __shfl_xor(d, m, W);
+        const int oi = __shfl_xor(i, m, W);
         if (od < d || (od == d && oi < i)) {
             d = od;
             i = oi;
@@ -179,44 +254,127 @@ __device__ __forceinline__ void min_pair32(float& d, int& i) {
     }
 }
 
-__global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ desc_base,
-                                                      const FrameCounters* __restrict__ cnt, int cap,
-                                                      const int2* __restrict__ pair_frames,
-                                                      const int* __restrict__ cand_idx, int* __restrict__ knn_idx,
-                                                      float* __restrict__ knn_dist) {
+__device__ __forceinline__ void knn_store(int* __restrict__ knn_idx, float* __restrict__ knn_dist, size_t o, float d0, int i0,
+                                          float d1, int i1) {
+    const bool h0 = i0 != 0x7fffffff, h1 = i1 != 0x7fffffff;
+    knn_idx[o] = h0 ? i0 : -1;
+    knn_idx[o + 1] = h1 ? i1 : -1;
+    knn_dist[o] = h0 ? sqrtf(d0) : FLT_MAX;
+    knn_dist[o + 1] = h1 ? sqrtf(d1) : FLT_MAX;
+}
+
+// Bound on |MFMA score - exact score| + the float error of the sequential distance, for unit-norm operands: split
+// residue 3 * 2^-18, FP32 accumulation of 193 terms, norms and the re-scored distance itself.  Scaled by the operands' norms.
+constexpr float kCertMargin = 2e-4f;
+
+// 32 lanes per query; candidate c of a query = row e of kept block k of group g, c = 12 g + 4 k + e
+__global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt, int cap,
+                                                      const int2* __restrict__ pair_frames, const int* __restrict__ cand_idx,
+                                                      const float* __restrict__ cand_val, const int* __restrict__ nmax_bits, int groups,
+                                                      float cert_scale, int* __restrict__ knn_idx, float* __restrict__ knn_dist,
+                                                      int* __restrict__ redo_list, int* __restrict__ redo_cnt) {
     const int pair = blockIdx.y;
     const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
     const int nA = min(cnt[fa].n_raw, cap), nB = min(cnt[fb].n_raw, cap);
     const int q = blockIdx.x * 8 + (threadIdx.x >> 5), sub = threadIdx.x & 31;
     if (q >= nA) return;
-    int idx = (nB > 0) ? cand_idx[((size_t)pair * cap + q) * kCand + sub] : -1;
-    float d = FLT_MAX;
-    if (idx >= 0) {
-        const float* a = desc_base + ((size_t)fa * cap + q) * 64;
-        const float* b = desc_base + ((size_t)fb * cap + idx) * 64;
+    const size_t co = ((size_t)pair * cap + q) * kCandStride;
+    const float* a = desc_base + ((size_t)fa * cap + q) * 64;
+    float b0 = FLT_MAX, b1 = FLT_MAX;  // this lane's two smallest (distance, row), lexicographic
+    int j0 = 0x7fffffff, j1 = 0x7fffffff;
+    for (int c = sub; c < groups * 4 * kKeep; c += 32) {
+        const int g = c / (4 * kKeep), k = (c - g * 4 * kKeep) >> 2, e = c & 3;
+        const int blk = cand_idx[co + g * 4 + k];
+        const int row = (blk >> 2) * 32 + 8 * (blk & 3) + 4 * (g & 1) + e;
+        if (blk < 0 || row >= nB) continue;
+        const float* b = desc_base + ((size_t)fb * cap + row) * 64;
         float s = 0.f;
 #pragma unroll 16
-        for (int k = 0; k < 64; k++) {  // sequential float accumulation: the oracle's normL2Sqr (A.7)
-            const float t = a[k] - b[k];
+        for (int kk = 0; kk < 64; kk++) {  // sequential float accumulation: the oracle's normL2Sqr (A.7)
+            const float t = a[kk] - b[kk];
             s += t * t;
         }
-        d = s;
-    } else {
-        idx = 0x7fffffff;
+        if (s < b0 || (s == b0 && row < j0)) {
+            b1 = b0, j1 = j0;
+            b0 = s, j0 = row;
+        } else if (s < b1 || (s == b1 && row < j1)) {
+            b1 = s, j1 = row;
+        }
     }
-    float d0 = d;
-    int i0 = idx;
-    min_pair32(d0, i0);
-    float d1 = (idx == i0) ? FLT_MAX : d;
-    int i1 = (idx == i0) ? 0x7fffffff : idx;
-    min_pair32(d1, i1);
+    float d0 = b0;
+    int i0 = j0;
+    min_pair<32>(d0, i0);
+    float d1 = (j0 == i0) ? b1 : b0;  // the winner lane offers its runner-up
+    int i1 = (j0 == i0) ? j1 : j0;
+    min_pair<32>(d1, i1);
+    // ||a||^2 (any summation order: it only enters the certificate, whose margin covers it)
+    float na2 = a[2 * sub] * a[2 * sub] + a[2 * sub + 1] * a[2 * sub + 1];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) na2 += __shfl_xor(na2, m, 32);
+    // certificate: t4 of a group bounds the score of every train row the group left out
+    bool doubt = false;
+    if (sub < groups && i1 != 0x7fffffff) {
+        const float t4 = cand_val[co + sub * 4 + 3];
+        const float bmax2 = __int_as_float(nmax_bits[fb]);
+        const float margin = cert_scale * kCertMargin * fmaxf(1.f, 0.5f * (na2 + bmax2));
+        doubt = t4 > -1e29f && !((na2 - 2.f * t4) > d1 + margin);
+    }
+    const unsigned long long m = __ballot(doubt) >> (threadIdx.x & 32) & 0xffffffffull;
     if (sub == 0) {
-        const size_t o = ((size_t)pair * cap + q) * 2;
-        const bool h0 = i0 != 0x7fffffff, h1 = i1 != 0x7fffffff;
-        knn_idx[o] = h0 ? i0 : -1;
-        knn_idx[o + 1] = h1 ? i1 : -1;
-        knn_dist[o] = h0 ? sqrtf(d0) : FLT_MAX;
-        knn_dist[o + 1] = h1 ? sqrtf(d1) : FLT_MAX;
+        knn_store(knn_idx, knn_dist, ((size_t)pair * cap + q) * 2, d0, i0, d1, i1);
+        if (m != 0ull) redo_list[atomicAdd(redo_cnt, 1)] = pair * cap + q;
+    }
+}
+
+// Exact 2-NN of the listed queries over ALL train rows: one wavefront per query, lane L takes rows L, L + 64, ...
+__global__ __launch_bounds__(64) void k_match_exact(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt, int cap,
+                                                    const int2* __restrict__ pair_frames, const int* __restrict__ redo_list,
+                                                    const int* __restrict__ redo_cnt, int* __restrict__ knn_idx,
+                                                    float* __restrict__ knn_dist) {
+    const int lane = threadIdx.x, total = *redo_cnt;
+    for (int e = blockIdx.x; e < total; e += gridDim.x) {
+        const int pq = redo_list[e], pair = pq / cap, q = pq - pair * cap;
+        const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
+        const int nB = min(cnt[fb].n_raw, cap);
+        float a[64];
+        const float4* ap = reinterpret_cast<const float4*>(desc_base + ((size_t)fa * cap + q) * 64);
+#pragma unroll
+        for (int k4 = 0; k4 < 16; k4++) {
+            const float4 v = ap[k4];
+            a[4 * k4] = v.x, a[4 * k4 + 1] = v.y, a[4 * k4 + 2] = v.z, a[4 * k4 + 3] = v.w;
+        }
+        float b0 = FLT_MAX, b1 = FLT_MAX;  // the lane's two smallest distances; rows come in ascending order, ties keep the earlier
+        int j0 = 0x7fffffff, j1 = 0x7fffffff;
+        for (int r = lane; r < nB; r += 64) {
+            const float4* bp = reinterpret_cast<const float4*>(desc_base + ((size_t)fb * cap + r) * 64);
+            float s = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < 16; k4++) {
+                const float4 v = bp[k4];
+                float t = a[4 * k4] - v.x;
+                s += t * t;
+                t = a[4 * k4 + 1] - v.y;
+                s += t * t;
+                t = a[4 * k4 + 2] - v.z;
+                s += t * t;
+                t = a[4 * k4 + 3] - v.w;
+                s += t * t;
+            }
+            if (s < b0) {
+                b1 = b0, j1 = j0;
+                b0 = s, j0 = r;
+            } else if (s < b1) {
+                b1 = s, j1 = r;
+            }
+        }
+        float d0 = b0;
+        int i0 = j0;
+        min_pair<64>(d0, i0);
+        // second: the winner lane offers its runner-up, the others their best
+        float d1 = (j0 == i0) ? b1 : b0;
+        int i1 = (j0 == i0) ? j1 : j0;
+        min_pair<64>(d1, i1);
+        if (lane == 0) knn_store(knn_idx, knn_dist, ((size_t)pair * cap + q) * 2, d0, i0, d1, i1);
     }
 }
 
@@ -296,22 +454,32 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
     const int cap = fs.cap, P = ps.P;
     {
         StageScope sc(ctx, ST_MATCH_PREP);
+        VO_HIP(hipMemsetAsync(fs.nmax, 0, (size_t)fs.F * sizeof(int), ctx->stream));
+        VO_HIP(hipMemsetAsync(ps.redo_cnt, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_match_prep, dim3(cap / 32, fs.F), dim3(64), 0, ctx->stream, fs.desc, fs.cnt, cap,
-                           reinterpret_cast<float4*>(fs.descT), fs.nrm);
+                           reinterpret_cast<float4*>(fs.descT), fs.nrm, fs.nmax);
         VO_HIP(hipGetLastError());
     }
+    // Train-range splits: one per query block when the batch alone fills the chip (long scans make top-4 insertions rare),
+    // four for a few pairs so that a single pair still spreads over 512 wavefronts.
+    constexpr int kQueryBlocks = 2;  // 64 queries per wavefront
+    const int ksplit = (P >= 8) ? 1 : 4;
     {
         StageScope sc(ctx, ST_MATCH_MFMA);
-        constexpr int kQueryBlocks = 2;  // 64 queries per wavefront (1 measured slower: 5.65 vs 5.25 ms)
-        const int waves = (cap / (32 * kQueryBlocks)) * kSplit;
-        hipLaunchKernelGGL(k_match_mfma<kQueryBlocks>, dim3(waves / 4, P), dim3(256), 0, ctx->stream, fs.desc,
-                           reinterpret_cast<const float4*>(fs.descT), fs.nrm, fs.cnt, cap, ps.frames, ps.cand_val, ps.cand_idx);
+        const int bpp = (cap / (32 * kQueryBlocks)) * ksplit / 4;  // workgroups (4 wavefronts) per pair
+        hipLaunchKernelGGL(k_match_bf3<kQueryBlocks>, dim3(bpp * P), dim3(256), 0, ctx->stream, fs.desc,
+                           reinterpret_cast<const uint4*>(fs.descT), fs.nrm, fs.cnt, cap, ps.frames, ksplit, bpp, (P % 8 == 0) ? 1 : 0,
+                           ps.cand_val, ps.cand_idx);
         VO_HIP(hipGetLastError());
     }
     {
         StageScope sc(ctx, ST_MATCH_SELECT);
-        hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames,
-                           ps.cand_idx, ps.knn_idx, ps.knn_dist);
+        const float cert_scale = ctx->force_exact_match ? 1e30f : 1.f;
+        ctx->last_redo_cnt = ps.redo_cnt;
+        hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.cand_idx,
+                           ps.cand_val, fs.nmax, 2 * ksplit, cert_scale, ps.knn_idx, ps.knn_dist, ps.redo_list, ps.redo_cnt);
+        hipLaunchKernelGGL(k_match_exact, dim3(2048), dim3(64), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.redo_list,
+                           ps.redo_cnt, ps.knn_idx, ps.knn_dist);
         if (filter) {
             const vo_params& p = ctx->prm;
             hipLaunchKernelGGL(k_match_filter, dim3(P), dim3(1024), 0, ctx->stream, fs.kp, fs.cnt, cap, ps.frames,
