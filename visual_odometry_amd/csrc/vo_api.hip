@@ -147,7 +147,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.kp, (size_t)F * cap));
     VO_TRY(dalloc(fs.rank, (size_t)F * cap));
     VO_TRY(dalloc(fs.desc, (size_t)F * cap * 64));
-    VO_TRY(dalloc(fs.descT, (size_t)F * cap * 64));
+    VO_TRY(dalloc(fs.descT, (size_t)F * cap * 72));  // 9 slabs of 32 B per row
     VO_TRY(dalloc(fs.nrm, (size_t)F * cap));
     VO_TRY(dalloc(fs.nmax, (size_t)F));
     VO_TRY(dalloc(fs.cnt, (size_t)F));

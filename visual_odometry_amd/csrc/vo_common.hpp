@@ -133,7 +133,7 @@ struct FrameSet {
     vo_keypoint* kp = nullptr;      // [F][cap] sorted
     int* rank = nullptr;            // [F][cap]
     float* desc = nullptr;          // [F][cap][64]
-    float* descT = nullptr;         // [F][cap/32][8][64] x 16 B: MFMA operand layout (bf16 high parts, bf16 low parts)
+    float* descT = nullptr;         // [F][cap/32][9][64] x 16 B: MFMA operand layout (bf16 high parts, low parts, norm term)
     float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
     int* nmax = nullptr;            // [F] bits of the largest ||b||^2 of the frame
     FrameCounters* cnt = nullptr;   // [F]

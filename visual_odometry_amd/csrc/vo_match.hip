@@ -51,8 +51,9 @@ __device__ __forceinline__ void bf16_split8(const float4& v0, const float4& v1, 
     lo = make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
 }
 
-// Operand layout of a 32-row tile: 8 slabs of 64 lanes x 16 bytes.  Lane (h, r) of slab m (0..3) holds the high parts of
-// row r, elements 32h + 8m .. + 7; slab 4 + m the low parts.
+constexpr int kSlabs = 9;
+// Operand layout of a 32-row tile: 9 slabs of 64 lanes x 16 bytes.  Lane (h, r) of slab m (0..3) holds the high parts of
+// row r, elements 32h + 8m .. + 7; slab 4 + m the low parts; slab 8 the norm term (below).
 __global__ __launch_bounds__(64) void k_match_prep(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt,
                                                    int cap, float4* __restrict__ descT_base, float* __restrict__ nrm_base,
                                                    int* __restrict__ nmax_bits) {
@@ -62,7 +63,7 @@ __global__ __launch_bounds__(64) void k_match_prep(const float* __restrict__ des
     const int lane = threadIdx.x, h = lane >> 5;
     const int r = tile * 32 + (lane & 31);
     const float4* row = reinterpret_cast<const float4*>(desc_base + ((size_t)frame * cap + r) * 64);
-    float4* out = descT_base + ((size_t)frame * (cap / 32) + tile) * 8 * 64;
+    float4* out = descT_base + ((size_t)frame * (cap / 32) + tile) * kSlabs * 64;
     float ss = 0.f;
     float4 v[8];
 #pragma unroll
@@ -79,7 +80,14 @@ __global__ __launch_bounds__(64) void k_match_prep(const float* __restrict__ des
         reinterpret_cast<uint4*>(out)[(4 + m) * 64 + lane] = lo;
     }
     ss += __shfl_xor(ss, 32, 64);
-    if (h == 0) nrm_base[(size_t)frame * cap + r] = (r < n) ? -0.5f * ss : -1e30f;
+    const float nb = (r < n) ? -0.5f * ss : -1e30f;
+    if (h == 0) nrm_base[(size_t)frame * cap + r] = nb;
+    {   // slab 8: -0.5||b||^2 as three bf16 (24 bits) in k slots 0..2 of lane half 0; the query side holds ones there
+        uint32_t p0, p1, p2, rest;
+        bf16_split(nb, p0, p1);
+        bf16_split(nb - __uint_as_float(p0 << 16) - __uint_as_float(p1 << 16), p2, rest);
+        reinterpret_cast<uint4*>(out)[8 * 64 + lane] = (h == 0) ? make_uint4(p0 | (p1 << 16), p2, 0u, 0u) : make_uint4(0u, 0u, 0u, 0u);
+    }
     // largest squared norm of the frame (non-negative floats order like their bit patterns): scales the certificate's margin
     float mx = (r < n) ? ss : 0.f;
 #pragma unroll
@@ -120,6 +128,50 @@ __device__ __forceinline__ float max4(float a, float b, float c, float d) {  // 
 
 constexpr int kKeep = 3;         // blocks kept per group
 constexpr int kCandStride = 32;  // slots per query in cand_val / cand_idx: 8 groups x (3 block ids | t4)
+
+// One shortlist check: block j (registers 4j .. 4j+3) of query block c of a finished accumulator tile
+template <int NC>
+__device__ __forceinline__ void bf3_check(const f32x16 (&acc)[NC], int c, int j, int tile, float (&bv)[NC][kKeep], int (&bi)[NC][kKeep],
+                                          float (&t4)[NC]) {
+    const float m = max4(acc[c][4 * j], acc[c][4 * j + 1], acc[c][4 * j + 2], acc[c][4 * j + 3]);
+    t4[c] = __builtin_amdgcn_fmed3f(m, bv[c][kKeep - 1], t4[c]);
+    if (__any(m > bv[c][kKeep - 1])) top3_insert(m, 4 * tile + j, bv[c], bi[c]);  // rarer and rarer as the scan goes on
+}
+
+// One step of the software pipeline: the 1 + 12 NC MFMAs of the tile whose operands sit in th / tl / tnrm go into `an`,
+// and BETWEEN them (an MFMA occupies the matrix pipe for 32 cycles, the wavefront is free to issue ~7 VALU instructions
+// meanwhile) the shortlist checks of the PREVIOUS tile's accumulators `ao`.  Each operand slab is re-loaded for the next
+// tile (tn) right after its last MFMA was issued.
+template <int NC, bool CHECK>
+__device__ __forceinline__ void bf3_step(f32x16 (&an)[NC], const f32x16 (&ao)[NC], Bf16Frag (&th)[4], Bf16Frag (&tl)[4], Bf16Frag& tnrm,
+                                         const Bf16Frag (&qh)[NC][4], const Bf16Frag (&ql)[NC][4], const uint4* __restrict__ tn,
+                                         int tile_prev, float (&bv)[NC][kKeep], int (&bi)[NC][kKeep], float (&t4)[NC]) {
+    static_assert(NC <= 3, "the checks of a block row are spread over the three partial products");
+    Bf16Frag ones;
+    ones.u = make_uint4(0x3f803f80u, 0x00003f80u, 0u, 0u);  // bf16 1, 1, 1, 0 ...: picks the three norm parts of slab 8
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the norm term first (accumulator input = literal zero: no register initialisation); both query blocks start from it
+    const f32x16 nterm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tnrm.v, ones.v, zero, 0, 0, 0);
+    tnrm.u = tn[8 * 64];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+#pragma unroll
+        for (int part = 0; part < 3; part++) {  // ah.bh, ah.bl (query low), al.bh (train low)
+#pragma unroll
+            for (int c = 0; c < NC; c++) {
+                const bf16x8 a = part == 2 ? tl[m].v : th[m].v, b = part == 1 ? ql[c][m].v : qh[c][m].v;
+                an[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, (m == 0 && part == 0) ? nterm : an[c], 0, 0, 0);
+            }
+            if (part == 1) th[m].u = tn[m * 64];
+            if (part == 2) tl[m].u = tn[(4 + m) * 64];
+#if defined(VO_EXP) && (VO_EXP == 4 || VO_EXP == 5)
+            if (CHECK && part < NC && tile_prev < 0) bf3_check<NC>(ao, part, m, tile_prev, bv, bi, t4);
+#else
+            if (CHECK && part < NC) bf3_check<NC>(ao, part, m, tile_prev, bv, bi, t4);
+#endif
+        }
+    }
+}
 
 template <int NC>  // 32-query blocks per wavefront
 __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ desc_base, const uint4* __restrict__ descT_base,
@@ -174,58 +226,50 @@ __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ des
             bi[c][k] = -1;
         }
     }
-    const uint4* __restrict__ descT = descT_base + (size_t)fb * (cap / 32) * 8 * 64;
-    const float* __restrict__ nrm = nrm_base + (size_t)fb * cap;
+    const uint4* __restrict__ descT = descT_base + (size_t)fb * (cap / 32) * kSlabs * 64;
 
-    // operands of the NEXT tile are re-loaded slab by slab right after the MFMAs that used the slab were issued
-    Bf16Frag th[4], tl[4];
-    float4 n4[4];
-    if (sp < ntiles) {
-        const uint4* tp = descT + (size_t)sp * 8 * 64 + lane;
+    // The workgroups of a pair start their scan at different tiles (and wrap around), so that first touches of operand
+    // tiles (HBM misses) are spread over the pair's workgroups instead of all being taken by whichever is in front.
+    Bf16Frag th[4], tl[4], tnrm;
+    const int nsteps = (ntiles - sp + ksplit - 1) / ksplit;  // tiles sp, sp + ksplit, ... of this wavefront's split
+    const int s0 = nsteps > 0 ? (int)(((long long)(bx / ksplit) * nsteps) / max(bpp / ksplit, 1)) % nsteps : 0;
+    auto tile_of = [&](int i) {  // tile of step i (i <= nsteps: step nsteps wraps to a harmless re-load of the first tile)
+        int sc = s0 + i;
+        sc = sc >= nsteps ? sc - nsteps : sc;
+        return sp + sc * ksplit;
+    };
+#if defined(VO_EXP) && VO_EXP == 5
+    auto slab = [&](int tile) { return descT + (size_t)(tile & 3) * kSlabs * 64 + lane; };
+#else
+    auto slab = [&](int tile) { return descT + (size_t)tile * kSlabs * 64 + lane; };
+#endif
+    if (nsteps > 0) {
+        const uint4* tp = slab(tile_of(0));
 #pragma unroll
         for (int m = 0; m < 4; m++) {
             th[m].u = tp[m * 64];
             tl[m].u = tp[(4 + m) * 64];
         }
-        // -0.5||b||^2 of the lane's 16 accumulator rows: register 4j + e is tile row 8j + 4h + e
-#pragma unroll
-        for (int j = 0; j < 4; j++) n4[j] = *reinterpret_cast<const float4*>(nrm + sp * 32 + 8 * j + 4 * h);
-    }
-    for (int t = sp; t < ntiles; t += ksplit) {
-        const bool more = t + ksplit < ntiles;
-        const int tn_i = more ? t + ksplit : t;
-        const uint4* tn = descT + (size_t)tn_i * 8 * 64 + lane;
-        f32x16 acc[NC];
-#pragma unroll
-        for (int c = 0; c < NC; c++)
-#pragma unroll
-            for (int j = 0; j < 4; j++) {
-                acc[c][4 * j + 0] = n4[j].x;
-                acc[c][4 * j + 1] = n4[j].y;
-                acc[c][4 * j + 2] = n4[j].z;
-                acc[c][4 * j + 3] = n4[j].w;
-            }
-#pragma unroll
-        for (int j = 0; j < 4; j++) n4[j] = *reinterpret_cast<const float4*>(nrm + tn_i * 32 + 8 * j + 4 * h);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-#pragma unroll
-            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[m].v, qh[c][m].v, acc[c], 0, 0, 0);
-#pragma unroll
-            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(th[m].v, ql[c][m].v, acc[c], 0, 0, 0);
-            th[m].u = tn[m * 64];
-#pragma unroll
-            for (int c = 0; c < NC; c++) acc[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tl[m].v, qh[c][m].v, acc[c], 0, 0, 0);
-            tl[m].u = tn[(4 + m) * 64];
+        tnrm.u = tp[8 * 64];
+        // two accumulator sets: while the MFMAs of step i fill one, the checks of step i - 1 read the other
+        f32x16 accA[NC], accB[NC];
+        bf3_step<NC, false>(accA, accB, th, tl, tnrm, qh, ql, slab(tile_of(1)), 0, bv, bi, t4);
+        int i = 1;
+        for (; i + 1 < nsteps; i += 2) {
+            bf3_step<NC, true>(accB, accA, th, tl, tnrm, qh, ql, slab(tile_of(i + 1)), tile_of(i - 1), bv, bi, t4);
+            bf3_step<NC, true>(accA, accB, th, tl, tnrm, qh, ql, slab(tile_of(i + 2)), tile_of(i), bv, bi, t4);
         }
+        if (i < nsteps) {  // one more tile: into B, then B's checks
+            bf3_step<NC, true>(accB, accA, th, tl, tnrm, qh, ql, slab(tile_of(i + 1)), tile_of(i - 1), bv, bi, t4);
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+            for (int j = 0; j < 4; j++)
 #pragma unroll
-            for (int c = 0; c < NC; c++) {
-                const float m = max4(acc[c][4 * j], acc[c][4 * j + 1], acc[c][4 * j + 2], acc[c][4 * j + 3]);
-                t4[c] = __builtin_amdgcn_fmed3f(m, bv[c][kKeep - 1], t4[c]);
-                if (__any(m > bv[c][kKeep - 1])) top3_insert(m, 4 * t + j, bv[c], bi[c]);  // rare after the first tiles
-            }
+                for (int c = 0; c < NC; c++) bf3_check<NC>(accB, c, j, tile_of(i), bv, bi, t4);
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++)
+#pragma unroll
+                for (int c = 0; c < NC; c++) bf3_check<NC>(accA, c, j, tile_of(i - 1), bv, bi, t4);
         }
     }
 #pragma unroll
