@@ -154,3 +154,26 @@ def test_replay_follows_the_node_loop(ctx):
             Rtot = Rtot @ r["R"].T
     np.testing.assert_allclose(last["orientation"], Rtot, atol=1e-12)
     assert last["estimate_pos"][0] > 1.0
+
+
+def test_batch_of_eight_takes_the_unsplit_matcher_path(ctx):
+    """Eight pairs or more: one train split per workgroup and one pair per XCD (k_match_bf3 with ksplit = 1); fewer pairs
+    split the train range four ways.  Both must give the oracle's matches, with ragged keypoint counts."""
+    scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in
+              [(700, 11), (150, 12), (900, 13), (40, 14), (500, 15), (650, 16), (300, 17), (800, 18)]]
+    b = Batch(ctx, len(scenes), 480, 640)
+    for i, sc in enumerate(scenes):
+        b.set_pair(i, sc.img1, sc.img2, sc.K)
+    b.run()
+    b.sync()
+    for i, sc in enumerate(scenes):
+        out = b.get(i)
+        p1, p2, m, mask, X = b.get_points(i)
+        single = ctx.opt_DetectFeatures(sc.img1, sc.img2)  # one pair: the four-way split
+        assert np.array_equal(p1, single.Kpoints1) and np.array_equal(p2, single.Kpoints2)
+        assert np.array_equal(m["trainIdx"], single.match["trainIdx"]) and np.array_equal(m["distance"], single.match["distance"])
+        if i in (0, 3):
+            rp1, rp2, rm = O.detect_match(sc.img1, sc.img2)
+            assert out.n_match == len(rm) and np.array_equal(p1, rp1) and np.array_equal(p2, rp2)
+            assert np.array_equal(m["distance"].view(np.uint32), rm["distance"].view(np.uint32))
+    b.close()

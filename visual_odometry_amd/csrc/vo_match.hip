@@ -138,37 +138,36 @@ __device__ __forceinline__ void bf3_check(const f32x16 (&acc)[NC], int c, int j,
     if (__any(m > bv[c][kKeep - 1])) top3_insert(m, 4 * tile + j, bv[c], bi[c]);  // rarer and rarer as the scan goes on
 }
 
-// One step of the software pipeline: the 1 + 12 NC MFMAs of the tile whose operands sit in th / tl / tnrm go into `an`,
-// and BETWEEN them (an MFMA occupies the matrix pipe for 32 cycles, the wavefront is free to issue ~7 VALU instructions
-// meanwhile) the shortlist checks of the PREVIOUS tile's accumulators `ao`.  Each operand slab is re-loaded for the next
-// tile (tn) right after its last MFMA was issued.
+// One step of the software pipeline: the 1 + 12 NC MFMAs of the tile staged in LDS (st) go into `an`, and BETWEEN them
+// (an MFMA occupies the matrix pipe for 32 cycles, the wavefront is free to issue ~7 VALU instructions meanwhile) the
+// shortlist checks of the PREVIOUS tile's accumulators `ao`.  Operand slabs are read from LDS one MFMA group ahead.
 template <int NC, bool CHECK>
-__device__ __forceinline__ void bf3_step(f32x16 (&an)[NC], const f32x16 (&ao)[NC], Bf16Frag (&th)[4], Bf16Frag (&tl)[4], Bf16Frag& tnrm,
-                                         const Bf16Frag (&qh)[NC][4], const Bf16Frag (&ql)[NC][4], const uint4* __restrict__ tn,
-                                         int tile_prev, float (&bv)[NC][kKeep], int (&bi)[NC][kKeep], float (&t4)[NC]) {
+__device__ __forceinline__ void bf3_step(f32x16 (&an)[NC], const f32x16 (&ao)[NC], const uint4* st, const Bf16Frag (&qh)[NC][4],
+                                         const Bf16Frag (&ql)[NC][4], int tile_prev, float (&bv)[NC][kKeep], int (&bi)[NC][kKeep],
+                                         float (&t4)[NC]) {
     static_assert(NC <= 3, "the checks of a block row are spread over the three partial products");
-    Bf16Frag ones;
+    Bf16Frag ones, tnrm, th[2], tl[2];
     ones.u = make_uint4(0x3f803f80u, 0x00003f80u, 0u, 0u);  // bf16 1, 1, 1, 0 ...: picks the three norm parts of slab 8
+    tnrm.u = st[8 * 64];
+    th[0].u = st[0];
+    tl[0].u = st[4 * 64];
     const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     // the norm term first (accumulator input = literal zero: no register initialisation); both query blocks start from it
     const f32x16 nterm = __builtin_amdgcn_mfma_f32_32x32x16_bf16(tnrm.v, ones.v, zero, 0, 0, 0);
-    tnrm.u = tn[8 * 64];
 #pragma unroll
     for (int m = 0; m < 4; m++) {
+        if (m < 3) {
+            th[(m + 1) & 1].u = st[(m + 1) * 64];
+            tl[(m + 1) & 1].u = st[(5 + m) * 64];
+        }
 #pragma unroll
         for (int part = 0; part < 3; part++) {  // ah.bh, ah.bl (query low), al.bh (train low)
 #pragma unroll
             for (int c = 0; c < NC; c++) {
-                const bf16x8 a = part == 2 ? tl[m].v : th[m].v, b = part == 1 ? ql[c][m].v : qh[c][m].v;
+                const bf16x8 a = part == 2 ? tl[m & 1].v : th[m & 1].v, b = part == 1 ? ql[c][m].v : qh[c][m].v;
                 an[c] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, (m == 0 && part == 0) ? nterm : an[c], 0, 0, 0);
             }
-            if (part == 1) th[m].u = tn[m * 64];
-            if (part == 2) tl[m].u = tn[(4 + m) * 64];
-#if defined(VO_EXP) && (VO_EXP == 4 || VO_EXP == 5)
-            if (CHECK && part < NC && tile_prev < 0) bf3_check<NC>(ao, part, m, tile_prev, bv, bi, t4);
-#else
             if (CHECK && part < NC) bf3_check<NC>(ao, part, m, tile_prev, bv, bi, t4);
-#endif
         }
     }
 }
@@ -192,11 +191,12 @@ __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ des
     }
     const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
     const int nA = min(cnt[fa].n_raw, cap), nB = min(cnt[fb].n_raw, cap);
-    const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31;
-    const int w = bx * 4 + (threadIdx.x >> 6);
-    const int qb = w / ksplit, sp = w - qb * ksplit;
-    const int q0 = qb * 32 * NC;
-    if (q0 >= nA) return;
+    const int lane = threadIdx.x & 63, h = lane >> 5, l31 = lane & 31, wave = threadIdx.x >> 6;
+    // the four wavefronts of a workgroup take four consecutive query blocks and the SAME train split: they share every
+    // operand tile through LDS
+    const int qgroup = bx / ksplit, sp = bx - qgroup * ksplit;
+    const int q0 = (qgroup * 4 + wave) * 32 * NC;
+    if (qgroup * 4 * 32 * NC >= nA) return;  // no query in the whole workgroup (wavefronts past nA still help with the staging)
     const int ntiles = (nB + 31) >> 5;
 
     // query operands: the lane's query row, elements 32h + 8m .. + 7 for MFMA m (the same k permutation as the train side)
@@ -228,39 +228,56 @@ __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ des
     }
     const uint4* __restrict__ descT = descT_base + (size_t)fb * (cap / 32) * kSlabs * 64;
 
+    // Operand tiles (9 KB) go global -> registers -> LDS, each wavefront staging a quarter (slabs w and w + 4; wavefront 0
+    // also the norm slab), double-buffered: the loads of tile i + 1 are issued before the MFMAs of tile i and written to the
+    // other buffer after them, one barrier per step.  (Straight from L1 each wavefront pulled the whole 9 KB per step:
+    // 19 GB per launch through the 64 B/clk vector L1s, which held the MFMA pipe at half rate.)
     // The workgroups of a pair start their scan at different tiles (and wrap around), so that first touches of operand
-    // tiles (HBM misses) are spread over the pair's workgroups instead of all being taken by whichever is in front.
-    Bf16Frag th[4], tl[4], tnrm;
-    const int nsteps = (ntiles - sp + ksplit - 1) / ksplit;  // tiles sp, sp + ksplit, ... of this wavefront's split
-    const int s0 = nsteps > 0 ? (int)(((long long)(bx / ksplit) * nsteps) / max(bpp / ksplit, 1)) % nsteps : 0;
+    // tiles (HBM misses) are spread over the pair's workgroups.
+    __shared__ uint4 s_tile[2][kSlabs * 64];
+    const int nsteps = (ntiles - sp + ksplit - 1) / ksplit;  // tiles sp, sp + ksplit, ... of this workgroup's split
+    const int ngroups = max(bpp / ksplit, 1);
+    const int s0 = nsteps > 0 ? (int)(((long long)qgroup * nsteps) / ngroups) % nsteps : 0;
     auto tile_of = [&](int i) {  // tile of step i (i <= nsteps: step nsteps wraps to a harmless re-load of the first tile)
         int sc = s0 + i;
         sc = sc >= nsteps ? sc - nsteps : sc;
         return sp + sc * ksplit;
     };
-#if defined(VO_EXP) && VO_EXP == 5
-    auto slab = [&](int tile) { return descT + (size_t)(tile & 3) * kSlabs * 64 + lane; };
-#else
-    auto slab = [&](int tile) { return descT + (size_t)tile * kSlabs * 64 + lane; };
-#endif
+    uint4 g0, g1, g2 = make_uint4(0u, 0u, 0u, 0u);
+    auto stage_load = [&](int tile) {
+        const uint4* tp = descT + (size_t)tile * kSlabs * 64 + lane;
+        g0 = tp[wave * 64];
+        g1 = tp[(wave + 4) * 64];
+        if (wave == 0) g2 = tp[8 * 64];
+    };
+    auto stage_store = [&](int buf) {
+        s_tile[buf][wave * 64 + lane] = g0;
+        s_tile[buf][(wave + 4) * 64 + lane] = g1;
+        if (wave == 0) s_tile[buf][8 * 64 + lane] = g2;
+    };
     if (nsteps > 0) {
-        const uint4* tp = slab(tile_of(0));
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            th[m].u = tp[m * 64];
-            tl[m].u = tp[(4 + m) * 64];
-        }
-        tnrm.u = tp[8 * 64];
+        stage_load(tile_of(0));
+        stage_store(0);
+        __syncthreads();
         // two accumulator sets: while the MFMAs of step i fill one, the checks of step i - 1 read the other
         f32x16 accA[NC], accB[NC];
-        bf3_step<NC, false>(accA, accB, th, tl, tnrm, qh, ql, slab(tile_of(1)), 0, bv, bi, t4);
+        stage_load(tile_of(1));
+        bf3_step<NC, false>(accA, accB, &s_tile[0][lane], qh, ql, 0, bv, bi, t4);
+        stage_store(1);
+        __syncthreads();
         int i = 1;
-        for (; i + 1 < nsteps; i += 2) {
-            bf3_step<NC, true>(accB, accA, th, tl, tnrm, qh, ql, slab(tile_of(i + 1)), tile_of(i - 1), bv, bi, t4);
-            bf3_step<NC, true>(accA, accB, th, tl, tnrm, qh, ql, slab(tile_of(i + 2)), tile_of(i), bv, bi, t4);
+        for (; i + 1 < nsteps; i += 2) {  // i odd: tile i sits in buffer 1
+            stage_load(tile_of(i + 1));
+            bf3_step<NC, true>(accB, accA, &s_tile[1][lane], qh, ql, tile_of(i - 1), bv, bi, t4);
+            stage_store(0);
+            __syncthreads();
+            stage_load(tile_of(i + 2));
+            bf3_step<NC, true>(accA, accB, &s_tile[0][lane], qh, ql, tile_of(i), bv, bi, t4);
+            stage_store(1);
+            __syncthreads();
         }
         if (i < nsteps) {  // one more tile: into B, then B's checks
-            bf3_step<NC, true>(accB, accA, th, tl, tnrm, qh, ql, slab(tile_of(i + 1)), tile_of(i - 1), bv, bi, t4);
+            bf3_step<NC, true>(accB, accA, &s_tile[1][lane], qh, ql, tile_of(i - 1), bv, bi, t4);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -278,7 +295,10 @@ __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ des
         if (row < nA) {
             const size_t o = ((size_t)pair * cap + row) * kCandStride + (sp * 2 + h) * 4;
 #pragma unroll
-            for (int k = 0; k < kKeep; k++) cand_idx[o + k] = (bv[c][k] > -1e29f) ? bi[c][k] : -1;  // sentinel / all-padding blocks
+            for (int k = 0; k < kKeep; k++) {
+                cand_idx[o + k] = (bv[c][k] > -1e29f) ? bi[c][k] : -1;  // sentinel / all-padding blocks
+                cand_val[o + k] = bv[c][k];
+            }
             cand_val[o + 3] = t4[c];
         }
     }
@@ -324,13 +344,30 @@ __global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ 
     if (q >= nA) return;
     const size_t co = ((size_t)pair * cap + q) * kCandStride;
     const float* a = desc_base + ((size_t)fa * cap + q) * 64;
+    // ||a||^2 (any summation order: it only enters margins)
+    float na2 = a[2 * sub] * a[2 * sub] + a[2 * sub + 1] * a[2 * sub + 1];
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) na2 += __shfl_xor(na2, m, 32);
+    const float margin = cert_scale * kCertMargin * fmaxf(1.f, 0.5f * (na2 + __int_as_float(nmax_bits[fb])));
+    // Second largest of the kept blocks' maxima: two different rows score at least s2, so a block whose maximum lies more
+    // than the error margin below s2 cannot hold one of the two nearest rows and is not re-scored.
+    float bm = -FLT_MAX;  // lane sub < 4 * groups: slot sub of the query (k = 3 is t4, not a block)
+    if (sub < 4 * groups && (sub & 3) < kKeep && cand_idx[co + sub] >= 0) bm = cand_val[co + sub];
+    float s1 = bm, s2 = -FLT_MAX;
+#pragma unroll
+    for (int m = 16; m >= 1; m >>= 1) {  // (largest, second largest) of 32 lanes
+        const float o1 = __shfl_xor(s1, m, 32), o2 = __shfl_xor(s2, m, 32);
+        s2 = fmaxf(fminf(s1, o1), fmaxf(s2, o2));
+        s1 = fmaxf(s1, o1);
+    }
+    const float keep_from = s2 - margin;  // score units are half distance units: the full margin is twice what is needed
     float b0 = FLT_MAX, b1 = FLT_MAX;  // this lane's two smallest (distance, row), lexicographic
     int j0 = 0x7fffffff, j1 = 0x7fffffff;
     for (int c = sub; c < groups * 4 * kKeep; c += 32) {
         const int g = c / (4 * kKeep), k = (c - g * 4 * kKeep) >> 2, e = c & 3;
         const int blk = cand_idx[co + g * 4 + k];
         const int row = (blk >> 2) * 32 + 8 * (blk & 3) + 4 * (g & 1) + e;
-        if (blk < 0 || row >= nB) continue;
+        if (blk < 0 || row >= nB || cand_val[co + g * 4 + k] < keep_from) continue;
         const float* b = desc_base + ((size_t)fb * cap + row) * 64;
         float s = 0.f;
 #pragma unroll 16
@@ -351,16 +388,10 @@ __global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ 
     float d1 = (j0 == i0) ? b1 : b0;  // the winner lane offers its runner-up
     int i1 = (j0 == i0) ? j1 : j0;
     min_pair<32>(d1, i1);
-    // ||a||^2 (any summation order: it only enters the certificate, whose margin covers it)
-    float na2 = a[2 * sub] * a[2 * sub] + a[2 * sub + 1] * a[2 * sub + 1];
-#pragma unroll
-    for (int m = 16; m >= 1; m >>= 1) na2 += __shfl_xor(na2, m, 32);
     // certificate: t4 of a group bounds the score of every train row the group left out
     bool doubt = false;
     if (sub < groups && i1 != 0x7fffffff) {
         const float t4 = cand_val[co + sub * 4 + 3];
-        const float bmax2 = __int_as_float(nmax_bits[fb]);
-        const float margin = cert_scale * kCertMargin * fmaxf(1.f, 0.5f * (na2 + bmax2));
         doubt = t4 > -1e29f && !((na2 - 2.f * t4) > d1 + margin);
     }
     const unsigned long long m = __ballot(doubt) >> (threadIdx.x & 32) & 0xffffffffull;
@@ -370,12 +401,14 @@ __global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ 
     }
 }
 
-// Exact 2-NN of the listed queries over ALL train rows: one wavefront per query, lane L takes rows L, L + 64, ...
-__global__ __launch_bounds__(64) void k_match_exact(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt, int cap,
-                                                    const int2* __restrict__ pair_frames, const int* __restrict__ redo_list,
-                                                    const int* __restrict__ redo_cnt, int* __restrict__ knn_idx,
-                                                    float* __restrict__ knn_dist) {
-    const int lane = threadIdx.x, total = *redo_cnt;
+// Exact 2-NN of the listed queries over ALL train rows: one 256-thread workgroup per query, thread T takes rows T, T + 256, ...
+__global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt, int cap,
+                                                     const int2* __restrict__ pair_frames, const int* __restrict__ redo_list,
+                                                     const int* __restrict__ redo_cnt, int* __restrict__ knn_idx,
+                                                     float* __restrict__ knn_dist) {
+    __shared__ float s_d[4][2];
+    __shared__ int s_i[4][2];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, total = *redo_cnt;
     for (int e = blockIdx.x; e < total; e += gridDim.x) {
         const int pq = redo_list[e], pair = pq / cap, q = pq - pair * cap;
         const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
@@ -387,9 +420,9 @@ __global__ __launch_bounds__(64) void k_match_exact(const float* __restrict__ de
             const float4 v = ap[k4];
             a[4 * k4] = v.x, a[4 * k4 + 1] = v.y, a[4 * k4 + 2] = v.z, a[4 * k4 + 3] = v.w;
         }
-        float b0 = FLT_MAX, b1 = FLT_MAX;  // the lane's two smallest distances; rows come in ascending order, ties keep the earlier
+        float b0 = FLT_MAX, b1 = FLT_MAX;  // the thread's two smallest distances; rows come in ascending order, ties keep the earlier
         int j0 = 0x7fffffff, j1 = 0x7fffffff;
-        for (int r = lane; r < nB; r += 64) {
+        for (int r = tid; r < nB; r += 256) {
             const float4* bp = reinterpret_cast<const float4*>(desc_base + ((size_t)fb * cap + r) * 64);
             float s = 0.f;
 #pragma unroll
@@ -414,11 +447,31 @@ __global__ __launch_bounds__(64) void k_match_exact(const float* __restrict__ de
         float d0 = b0;
         int i0 = j0;
         min_pair<64>(d0, i0);
-        // second: the winner lane offers its runner-up, the others their best
-        float d1 = (j0 == i0) ? b1 : b0;
+        float d1 = (j0 == i0) ? b1 : b0;  // the winner lane offers its runner-up, the others their best
         int i1 = (j0 == i0) ? j1 : j0;
         min_pair<64>(d1, i1);
-        if (lane == 0) knn_store(knn_idx, knn_dist, ((size_t)pair * cap + q) * 2, d0, i0, d1, i1);
+        if (lane == 0) {
+            s_d[wave][0] = d0, s_i[wave][0] = i0;
+            s_d[wave][1] = d1, s_i[wave][1] = i1;
+        }
+        __syncthreads();
+        if (tid == 0) {  // merge four sorted pairs, (distance, row) lexicographic
+            float m0 = FLT_MAX, m1 = FLT_MAX;
+            int n0 = 0x7fffffff, n1 = 0x7fffffff;
+            for (int w = 0; w < 4; w++)
+                for (int k = 0; k < 2; k++) {
+                    const float d = s_d[w][k];
+                    const int i = s_i[w][k];
+                    if (d < m0 || (d == m0 && i < n0)) {
+                        m1 = m0, n1 = n0;
+                        m0 = d, n0 = i;
+                    } else if (d < m1 || (d == m1 && i < n1)) {
+                        m1 = d, n1 = i;
+                    }
+                }
+            knn_store(knn_idx, knn_dist, ((size_t)pair * cap + q) * 2, m0, n0, m1, n1);
+        }
+        __syncthreads();
     }
 }
 
@@ -510,7 +563,7 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
     const int ksplit = (P >= 8) ? 1 : 4;
     {
         StageScope sc(ctx, ST_MATCH_MFMA);
-        const int bpp = (cap / (32 * kQueryBlocks)) * ksplit / 4;  // workgroups (4 wavefronts) per pair
+        const int bpp = ((cap + 128 * kQueryBlocks - 1) / (128 * kQueryBlocks)) * ksplit;  // workgroups per pair: 4 query blocks of 64, one train split each
         hipLaunchKernelGGL(k_match_bf3<kQueryBlocks>, dim3(bpp * P), dim3(256), 0, ctx->stream, fs.desc,
                            reinterpret_cast<const uint4*>(fs.descT), fs.nrm, fs.cnt, cap, ps.frames, ksplit, bpp, (P % 8 == 0) ? 1 : 0,
                            ps.cand_val, ps.cand_idx);
@@ -522,7 +575,7 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
         ctx->last_redo_cnt = ps.redo_cnt;
         hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.cand_idx,
                            ps.cand_val, fs.nmax, 2 * ksplit, cert_scale, ps.knn_idx, ps.knn_dist, ps.redo_list, ps.redo_cnt);
-        hipLaunchKernelGGL(k_match_exact, dim3(2048), dim3(64), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.redo_list,
+        hipLaunchKernelGGL(k_match_exact, dim3(1024), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.redo_list,
                            ps.redo_cnt, ps.knn_idx, ps.knn_dist);
         if (filter) {
             const vo_params& p = ctx->prm;
