@@ -177,3 +177,56 @@ def test_batch_of_eight_takes_the_unsplit_matcher_path(ctx):
             assert out.n_match == len(rm) and np.array_equal(p1, rp1) and np.array_equal(p2, rp2)
             assert np.array_equal(m["distance"].view(np.uint32), rm["distance"].view(np.uint32))
     b.close()
+
+
+def test_bag_to_poses_end_to_end(ctx, tmp_path):
+    """N4 + N2 + N1 together: a rosbag with CompressedImage (PNG) frames and altitudes -> bagio -> get_image on the device
+    -> sequence batches -> the node loop.  Must equal the replay of the same frames preprocessed by the CPU restatement."""
+    import io
+
+    from PIL import Image
+
+    from visual_odometry_amd import bagio, chain, replay
+    from visual_odometry_amd import prep as P
+
+    step = 0.45
+    poses = [((0, 0, 0), (0, 0, 0)), ((0.5, -0.3, 1.0), (step, 0.02, 0.0)), ((1.0, 0.2, 2.0), (2 * step, 0.05, 0.02)),
+             ((1.0, 0.2, 2.0), (2 * step, 0.05, 0.02)), ((0.8, 0.5, 3.0), (3 * step, 0.0, 0.03))]
+    sc = synth.sequence_scene(480, 640, synth.K_PARETE, 900, 4004, poses)
+    # the "camera": 960 x 1280 colour frames (the gray scene on all three channels, pixel-doubled)
+    big = [np.repeat(np.repeat(np.stack([f, f, f], -1), 2, axis=0), 2, axis=1) for f in sc.frames]
+    alt_def = f"Header header\nfloat32 altitude\nbool validity\n{'=' * 80}\nMSG: std_msgs/Header\n{bagio.HEADER_DEF}"
+    path = str(tmp_path / "run.bag")
+    w = bagio.BagWriter(path, "bz2", chunk_bytes=1 << 19)
+    w.add_connection("/pylon_camera/image_raw/compressed", "sensor_msgs/CompressedImage", bagio.COMPRESSED_IMAGE_DEF)
+    w.add_connection("/drivers/altitude", "marta_msgs/Altitude", alt_def)
+    ci = bagio.MsgCodec("sensor_msgs/CompressedImage", bagio.COMPRESSED_IMAGE_DEF)
+    al = bagio.MsgCodec("marta_msgs/Altitude", alt_def)
+    for i, f in enumerate(big):
+        b = io.BytesIO()
+        Image.fromarray(f[..., ::-1]).save(b, "PNG")
+        w.write("/drivers/altitude", 50 + 0.5 * i - 0.02, al.encode({"header": {"seq": i, "stamp": 50 + 0.5 * i - 0.02, "frame_id": ""}, "altitude": 7.0, "validity": True}))
+        w.write("/pylon_camera/image_raw/compressed", 50 + 0.5 * i, ci.encode({"header": {"seq": i, "stamp": 50 + 0.5 * i, "frame_id": "cam"}, "format": "png", "data": b.getvalue()}))
+    w.close()
+
+    frames, stamps, alts = bagio.read_sequence(path)
+    assert len(frames) == 5 and frames[0].shape == (960, 1280, 3) and np.allclose(alts, 7.0)
+    K_full = np.diag([2.0, 2.0, 1.0]) @ sc.K
+    K = P.updateCameraMatrix((960, 1280), 640, 480, K_full, ctx.lib)
+    pr = P.Prep(ctx, (960, 1280), 640, 480, K, [0.01, -0.005, 0.0002, -0.0002])
+    try:
+        recs = replay.replay(ctx, frames, stamps, alts, K, np.eye(3), np.zeros(3), chunk=3, prep=pr)
+        gray = [O.prep(pr.params, f)["gray"] for f in frames]
+        ref = replay.replay(ctx, gray, stamps, alts, K, np.eye(3), np.zeros(3), chunk=3)
+    finally:
+        pr.close()
+    assert [r["fail"] for r in recs] == [chain.SUCCESS, chain.SUCCESS, chain.NOT_MOVING, chain.SUCCESS]
+    assert [r["prev"] for r in recs] == [0, 1, 2, 2]
+    for a, b in zip(recs, ref):
+        assert a["fail"] == b["fail"] and a["prev"] == b["prev"] and a["n_matches"] == b["n_matches"]
+        if a["fail"] == chain.SUCCESS:
+            for k in ("R", "t", "estimate_pos", "estimate_rpy", "twist_linear", "orientation", "world_pointsW"):
+                assert np.array_equal(a[k], b[k]), k
+            assert a["SF"] == b["SF"]
+    Rgt, tgt, base = sc.relative(0, 1)
+    assert _angle(recs[0]["R"], Rgt) < 1.0

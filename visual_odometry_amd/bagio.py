@@ -1,0 +1,386 @@
+"""N4: bag / image-directory reader for the offline replay, no ROS installation needed.
+
+The reference is driven by `rosbag play` (launch/*.launch:8; the bags themselves are not in the repository): camera frames
+arrive as sensor_msgs/CompressedImage on /pylon_camera/image_raw/compressed and the scale comes from marta_msgs/Altitude on
+/drivers/altitude (src/visual_Odometry.cpp:190-196).  This module reads the rosbag 2.0 container directly (records,
+chunks with `none` or `bz2` compression, connection records), deserialises ANY message type from the message definition
+text each connection carries (so marta_msgs needs no generated code), decodes JPEG / PNG payloads with Pillow on the host,
+and returns what visual_odometry_amd.replay.replay() takes.  `BagWriter` exists for tests and for making small fixtures.
+
+Format reference: the rosbag "Bags/Format/2.0" specification (record = header_len, header fields `len name=value`,
+data_len, data; op codes 2 message, 3 bag header, 4 index, 5 chunk, 6 chunk info, 7 connection) and the ROS 1 wire
+serialisation (little endian, strings and variable arrays with a uint32 count).
+"""
+from __future__ import annotations
+
+import bz2
+import io
+import os
+import struct
+
+import numpy as np
+
+MAGIC = b"#ROSBAG V2.0\n"
+OP_MSG, OP_BAG_HEADER, OP_INDEX, OP_CHUNK, OP_CHUNK_INFO, OP_CONNECTION = 2, 3, 4, 5, 6, 7
+
+_PRIM = {"bool": "?", "int8": "b", "uint8": "B", "byte": "b", "char": "B", "int16": "h", "uint16": "H", "int32": "i",
+         "uint32": "I", "int64": "q", "uint64": "Q", "float32": "f", "float64": "d"}
+
+HEADER_DEF = "uint32 seq\ntime stamp\nstring frame_id\n"
+
+
+# ------------------------------------------------------------------------------------------------ message definitions
+class MsgCodec:
+    """(De)serialiser built from a connection's message_definition text."""
+
+    def __init__(self, msg_type: str, definition: str):
+        self.msg_type = msg_type
+        self.types: dict[str, list[tuple[str, str, int | None]]] = {}
+        parts = definition.split("\n" + "=" * 80 + "\n")
+        self.types[msg_type] = self._parse(parts[0])
+        for p in parts[1:]:
+            head, _, body = p.partition("\n")
+            if head.startswith("MSG:"):
+                self.types[head[4:].strip()] = self._parse(body)
+        self.types.setdefault("std_msgs/Header", self._parse(HEADER_DEF))
+
+    @staticmethod
+    def _parse(text):
+        fields = []
+        for line in text.splitlines():
+            line = line.split("#", 1)[0].strip()
+            if not line:
+                continue
+            toks = line.split()
+            if len(toks) < 2 or "=" in toks[1] or (len(toks) > 2 and toks[2].startswith("=")):
+                continue  # constant
+            ftype, name = toks[0], toks[1]
+            count = None  # scalar
+            if ftype.endswith("]"):
+                base, _, n = ftype[:-1].partition("[")
+                ftype, count = base, (int(n) if n else -1)  # -1 = variable length
+            fields.append((ftype, name, count))
+        return fields
+
+    def _resolve(self, ftype, scope):
+        if ftype in self.types:
+            return ftype
+        if ftype == "Header":
+            return "std_msgs/Header"
+        pkg = scope.split("/")[0]
+        if f"{pkg}/{ftype}" in self.types:
+            return f"{pkg}/{ftype}"
+        for k in self.types:
+            if k.endswith("/" + ftype):
+                return k
+        raise KeyError(f"message type {ftype} is not described by the connection's definition")
+
+    # ---- decode
+    def decode(self, buf: bytes):
+        val, off = self._dec_type(self.msg_type, memoryview(buf), 0)
+        return val
+
+    def _dec_one(self, ftype, scope, mv, off):
+        if ftype in _PRIM:
+            fmt = "<" + _PRIM[ftype]
+            return struct.unpack_from(fmt, mv, off)[0], off + struct.calcsize(fmt)
+        if ftype == "string":
+            n = struct.unpack_from("<I", mv, off)[0]
+            return bytes(mv[off + 4:off + 4 + n]).decode("utf-8", "replace"), off + 4 + n
+        if ftype in ("time", "duration"):
+            s, ns = struct.unpack_from("<II" if ftype == "time" else "<ii", mv, off)
+            return s + ns * 1e-9, off + 8
+        return self._dec_type(self._resolve(ftype, scope), mv, off)
+
+    def _dec_type(self, tname, mv, off):
+        out = {}
+        for ftype, name, count in self.types[tname]:
+            if count is None:
+                out[name], off = self._dec_one(ftype, tname, mv, off)
+                continue
+            n = count
+            if n < 0:
+                n = struct.unpack_from("<I", mv, off)[0]
+                off += 4
+            if ftype in ("uint8", "char"):
+                out[name] = bytes(mv[off:off + n])
+                off += n
+            elif ftype in _PRIM:
+                dt = np.dtype("<" + {"?": "u1"}.get(_PRIM[ftype], np.dtype(_PRIM[ftype]).str[1:]))
+                out[name] = np.frombuffer(mv, dt, n, off).copy()
+                off += n * dt.itemsize
+            else:
+                items = []
+                for _ in range(n):
+                    v, off = self._dec_one(ftype, tname, mv, off)
+                    items.append(v)
+                out[name] = items
+        return out, off
+
+    # ---- encode (tests / fixtures)
+    def encode(self, msg: dict) -> bytes:
+        b = io.BytesIO()
+        self._enc_type(self.msg_type, msg, b)
+        return b.getvalue()
+
+    def _enc_one(self, ftype, scope, v, b):
+        if ftype in _PRIM:
+            b.write(struct.pack("<" + _PRIM[ftype], v))
+        elif ftype == "string":
+            raw = v.encode("utf-8")
+            b.write(struct.pack("<I", len(raw)) + raw)
+        elif ftype in ("time", "duration"):
+            s = int(np.floor(v))
+            b.write(struct.pack("<II" if ftype == "time" else "<ii", s, int(round((v - s) * 1e9))))
+        else:
+            self._enc_type(self._resolve(ftype, scope), v, b)
+
+    def _enc_type(self, tname, msg, b):
+        for ftype, name, count in self.types[tname]:
+            v = msg[name]
+            if count is None:
+                self._enc_one(ftype, tname, v, b)
+                continue
+            if count < 0:
+                b.write(struct.pack("<I", len(v)))
+            if ftype in ("uint8", "char"):
+                b.write(bytes(v))
+            elif ftype in _PRIM:
+                b.write(np.asarray(v, np.dtype("<" + np.dtype(_PRIM[ftype]).str[1:])).tobytes())
+            else:
+                for item in v:
+                    self._enc_one(ftype, tname, item, b)
+
+
+# ------------------------------------------------------------------------------------------------ container
+def _read_header(mv, off):
+    hlen = struct.unpack_from("<I", mv, off)[0]
+    off += 4
+    end, fields = off + hlen, {}
+    while off < end:
+        flen = struct.unpack_from("<I", mv, off)[0]
+        raw = bytes(mv[off + 4:off + 4 + flen])
+        name, _, value = raw.partition(b"=")
+        fields[name.decode()] = value
+        off += 4 + flen
+    return fields, end
+
+
+def _records(mv, off, end):
+    while off + 8 <= end:
+        fields, off = _read_header(mv, off)
+        dlen = struct.unpack_from("<I", mv, off)[0]
+        yield fields, mv[off + 4:off + 4 + dlen]
+        off += 4 + dlen
+
+
+class Connection:
+    def __init__(self, conn_id, topic, hdr):
+        self.id, self.topic = conn_id, topic
+        self.type = hdr.get("type", b"").decode()
+        self.md5sum = hdr.get("md5sum", b"").decode()
+        self.definition = hdr.get("message_definition", b"").decode("utf-8", "replace")
+        self._codec = None
+
+    @property
+    def codec(self) -> MsgCodec:
+        if self._codec is None:
+            self._codec = MsgCodec(self.type, self.definition)
+        return self._codec
+
+
+class BagReader:
+    """Sequential reader: for topic, conn, t, raw in BagReader(path).messages(topics): ...  (t in seconds, bag receive time)."""
+
+    def __init__(self, path):
+        self.path = path
+        self.data = np.memmap(path, np.uint8, "r") if os.path.getsize(path) else np.zeros(0, np.uint8)
+        mv = memoryview(self.data)
+        if bytes(mv[:len(MAGIC)]) != MAGIC:
+            raise ValueError(f"{path}: not a rosbag 2.0 file")
+        self.connections: dict[int, Connection] = {}
+        fields, data = next(_records(mv, len(MAGIC), len(mv)))
+        if fields.get("op") != bytes([OP_BAG_HEADER]):
+            raise ValueError("first record is not the bag header")
+        self.index_pos = struct.unpack("<Q", fields["index_pos"])[0]
+        self.conn_count = struct.unpack("<I", fields["conn_count"])[0]
+        self.chunk_count = struct.unpack("<I", fields["chunk_count"])[0]
+
+    def _add_connection(self, fields, data):
+        cid = struct.unpack("<I", fields["conn"])[0]
+        if cid not in self.connections:
+            hdr, _ = _read_header(memoryview(struct.pack("<I", len(data)) + bytes(data)), 0)
+            self.connections[cid] = Connection(cid, fields["topic"].decode(), hdr)
+
+    def _scan(self, mv, off, end, topics):
+        for fields, data in _records(mv, off, end):
+            op = fields["op"][0]
+            if op == OP_CONNECTION:
+                self._add_connection(fields, data)
+            elif op == OP_MSG:
+                conn = self.connections[struct.unpack("<I", fields["conn"])[0]]
+                if topics is None or conn.topic in topics:
+                    s, ns = struct.unpack("<II", fields["time"])
+                    yield conn.topic, conn, s + ns * 1e-9, bytes(data)
+            elif op == OP_CHUNK:
+                comp = fields["compression"].decode()
+                if comp == "none":
+                    inner = data
+                elif comp == "bz2":
+                    inner = memoryview(bz2.decompress(bytes(data)))
+                else:
+                    raise NotImplementedError(f"chunk compression '{comp}' (only none and bz2)")
+                yield from self._scan(inner, 0, len(inner), topics)
+
+    def messages(self, topics=None):
+        mv = memoryview(self.data)
+        first = next(_records(mv, len(MAGIC), len(mv)))  # skip the (padded) bag header record
+        hlen = struct.unpack_from("<I", mv, len(MAGIC))[0]
+        off = len(MAGIC) + 4 + hlen + 4 + len(first[1])
+        yield from self._scan(mv, off, len(mv), set(topics) if topics is not None else None)
+
+    def info(self):
+        counts: dict[str, int] = {}
+        t0 = t1 = None
+        for topic, conn, t, _ in self.messages():
+            counts[topic] = counts.get(topic, 0) + 1
+            t0 = t if t0 is None else min(t0, t)
+            t1 = t if t1 is None else max(t1, t)
+        return {"topics": {c.topic: (c.type, counts.get(c.topic, 0)) for c in self.connections.values()}, "start": t0, "end": t1}
+
+
+class BagWriter:
+    """Minimal rosbag 2.0 writer (tests, fixtures): one chunk per `chunk_bytes` of messages, index + chunk-info records."""
+
+    def __init__(self, path, compression="none", chunk_bytes=1 << 20):
+        assert compression in ("none", "bz2")
+        self.f = open(path, "wb")
+        self.compression, self.chunk_bytes = compression, chunk_bytes
+        self.conns: dict[str, tuple[int, bytes, bytes]] = {}
+        self.chunk = io.BytesIO()
+        self.chunk_index: dict[int, list[tuple[int, int, int]]] = {}
+        self.chunk_infos = []
+        self.f.write(MAGIC)
+        self._write_bag_header(0, 0, 0)
+
+    @staticmethod
+    def _rec(fields: dict, data: bytes) -> bytes:
+        h = b"".join(struct.pack("<I", len(k) + 1 + len(v)) + k.encode() + b"=" + v for k, v in fields.items())
+        return struct.pack("<I", len(h)) + h + struct.pack("<I", len(data)) + data
+
+    def _write_bag_header(self, index_pos, conn_count, chunk_count):
+        fields = {"op": bytes([OP_BAG_HEADER]), "index_pos": struct.pack("<Q", index_pos), "conn_count": struct.pack("<I", conn_count),
+                  "chunk_count": struct.pack("<I", chunk_count)}
+        h = self._rec(fields, b"")
+        pad = 4096 - len(h)
+        self.f.seek(len(MAGIC))
+        self.f.write(h[:-4] + struct.pack("<I", pad) + b" " * pad)
+
+    def add_connection(self, topic, msg_type, definition, md5sum="*"):
+        if topic not in self.conns:
+            cid = len(self.conns)
+            chdr = {"topic": topic.encode(), "type": msg_type.encode(), "md5sum": md5sum.encode(), "message_definition": definition.encode()}
+            data = b"".join(struct.pack("<I", len(k) + 1 + len(v)) + k.encode() + b"=" + v for k, v in chdr.items())
+            rec = self._rec({"op": bytes([OP_CONNECTION]), "conn": struct.pack("<I", cid), "topic": topic.encode()}, data)
+            self.conns[topic] = (cid, rec, b"")
+            self.chunk.write(rec)
+        return self.conns[topic][0]
+
+    def write(self, topic, t, raw: bytes):
+        cid = self.conns[topic][0]
+        s = int(np.floor(t))
+        tt = struct.pack("<II", s, int(round((t - s) * 1e9)))
+        self.chunk_index.setdefault(cid, []).append((struct.unpack("<Q", tt)[0], self.chunk.tell(), t))
+        self.chunk.write(self._rec({"op": bytes([OP_MSG]), "conn": struct.pack("<I", cid), "time": tt}, raw))
+        if self.chunk.tell() >= self.chunk_bytes:
+            self._flush()
+
+    def _flush(self):
+        raw = self.chunk.getvalue()
+        if not self.chunk_index:
+            return
+        pos = self.f.tell()
+        body = bz2.compress(raw) if self.compression == "bz2" else raw
+        self.f.write(self._rec({"op": bytes([OP_CHUNK]), "compression": self.compression.encode(), "size": struct.pack("<I", len(raw))}, body))
+        times = []
+        for cid, entries in self.chunk_index.items():
+            data = b"".join(struct.pack("<QI", tt, off) for tt, off, _ in entries)
+            self.f.write(self._rec({"op": bytes([OP_INDEX]), "ver": struct.pack("<I", 1), "conn": struct.pack("<I", cid),
+                                    "count": struct.pack("<I", len(entries))}, data))
+            times += [tt for tt, _, _ in entries]
+        self.chunk_infos.append((pos, min(times), max(times), {c: len(e) for c, e in self.chunk_index.items()}))
+        self.chunk, self.chunk_index = io.BytesIO(), {}
+
+    def close(self):
+        self._flush()
+        index_pos = self.f.tell()
+        for cid, rec, _ in self.conns.values():
+            self.f.write(rec)
+        for pos, t0, t1, counts in self.chunk_infos:
+            data = b"".join(struct.pack("<II", c, n) for c, n in counts.items())
+            self.f.write(self._rec({"op": bytes([OP_CHUNK_INFO]), "ver": struct.pack("<I", 1), "chunk_pos": struct.pack("<Q", pos),
+                                    "start_time": struct.pack("<Q", t0), "end_time": struct.pack("<Q", t1),
+                                    "count": struct.pack("<I", len(counts))}, data))
+        self._write_bag_header(index_pos, len(self.conns), len(self.chunk_infos))
+        self.f.close()
+
+
+# ------------------------------------------------------------------------------------------------ images
+COMPRESSED_IMAGE_DEF = "Header header\nstring format\nuint8[] data\n" + "=" * 80 + "\nMSG: std_msgs/Header\n" + HEADER_DEF
+IMAGE_DEF = ("Header header\nuint32 height\nuint32 width\nstring encoding\nuint8 is_bigendian\nuint32 step\nuint8[] data\n"
+             + "=" * 80 + "\nMSG: std_msgs/Header\n" + HEADER_DEF)
+
+
+def decode_image(msg: dict, msg_type: str) -> np.ndarray:
+    """The frame as cv_bridge's toCvCopy(msg, "bgr8") hands it to the node: H x W x 3 uint8, BGR (src/visual_Odometry.cpp:120)."""
+    if msg_type.endswith("CompressedImage"):
+        from PIL import Image
+
+        im = Image.open(io.BytesIO(msg["data"]))
+        rgb = np.asarray(im.convert("RGB"))
+        return np.ascontiguousarray(rgb[..., ::-1])
+    h, w, enc, step = msg["height"], msg["width"], msg["encoding"], msg["step"]
+    raw = np.frombuffer(msg["data"], np.uint8).reshape(h, step)
+    if enc == "bgr8":
+        return np.ascontiguousarray(raw[:, :3 * w].reshape(h, w, 3))
+    if enc == "rgb8":
+        return np.ascontiguousarray(raw[:, :3 * w].reshape(h, w, 3)[..., ::-1])
+    if enc == "mono8":
+        return np.ascontiguousarray(np.repeat(raw[:, :w, None], 3, axis=2))
+    raise NotImplementedError(f"image encoding {enc}")
+
+
+def read_sequence(path, image_topic="/pylon_camera/image_raw/compressed", altitude_topic="/drivers/altitude", altitude_field="altitude",
+                  max_frames=None, use_header_stamp=True):
+    """Frames, stamps [s] and the latest altitude at each frame, in bag order - the node's view of its topics
+    (it keeps the latest message of every topic, src/visual_Odometry.cpp:112-177)."""
+    bag = BagReader(path)
+    frames, stamps, alts = [], [], []
+    last_alt = float("nan")
+    for topic, conn, t, raw in bag.messages([image_topic, altitude_topic]):
+        msg = conn.codec.decode(raw)
+        if topic == altitude_topic:
+            last_alt = float(msg[altitude_field])
+            continue
+        frames.append(decode_image(msg, conn.type))
+        stamps.append(msg["header"]["stamp"] if use_header_stamp and "header" in msg else t)
+        alts.append(last_alt)
+        if max_frames is not None and len(frames) >= max_frames:
+            break
+    return frames, np.array(stamps), np.array(alts)
+
+
+def read_image_dir(path, fps=10.0, exts=(".png", ".jpg", ".jpeg", ".bmp", ".pgm", ".ppm")):
+    """Image-directory source for sites without bags: files in name order, BGR frames, stamps at a nominal rate."""
+    from PIL import Image
+
+    names = sorted(n for n in os.listdir(path) if n.lower().endswith(exts))
+    frames = [np.ascontiguousarray(np.asarray(Image.open(os.path.join(path, n)).convert("RGB"))[..., ::-1]) for n in names]
+    return frames, np.arange(len(frames)) / fps, names
+
+
+if __name__ == "__main__":
+    import json
+    import sys
+
+    print(json.dumps(BagReader(sys.argv[1]).info(), indent=1))

@@ -21,10 +21,17 @@ def _rotz(a):
 class _PairResults:
     """Results of pair (j, k): consecutive pairs come from the chunk's sequence batch, others are computed on demand."""
 
-    def __init__(self, ctx: Context, frames, K, chunk: int):
+    def __init__(self, ctx: Context, frames, K, chunk: int, prep=None):
         self.ctx, self.frames, self.K, self.chunk = ctx, frames, np.ascontiguousarray(K, np.float64), max(2, chunk)
         self.cache: dict[tuple[int, int], dict] = {}
-        self.h, self.w = frames[0].shape
+        self.prep = prep  # visual_odometry_amd.prep.Prep: frames are raw BGR and go through get_image on the device
+        self.h, self.w = (prep.params.dst_rows, prep.params.dst_cols) if prep is not None else frames[0].shape
+
+    def _put(self, batch, slot, frame):
+        if self.prep is not None:
+            self.prep.to_batch(frame, batch, slot)
+        elif isinstance(batch, Sequence):
+            batch.set_frame(slot, frame)
 
     @staticmethod
     def _collect(batch, p):
@@ -40,7 +47,7 @@ class _PairResults:
             return
         seq = Sequence(self.ctx, f1 - f0, self.h, self.w)
         for f in range(f0, f1):
-            seq.set_frame(f - f0, self.frames[f])
+            self._put(seq, f - f0, self.frames[f])
         for p in range(f1 - f0 - 1):
             seq.set_pair(p, p, p + 1, self.K)
         seq.run()
@@ -55,7 +62,12 @@ class _PairResults:
                 self._run_chunk(j)
             else:  # pair across a NOT_MOVING gap
                 b = Batch(self.ctx, 1, self.h, self.w)
-                b.set_pair(0, self.frames[j], self.frames[k], self.K)
+                if self.prep is not None:
+                    self._put(b, 0, self.frames[j])
+                    self._put(b, 1, self.frames[k])
+                    b.set_k(0, self.K)
+                else:
+                    b.set_pair(0, self.frames[j], self.frames[k], self.K)
                 b.run()
                 b.sync()
                 self.cache[(j, k)] = self._collect(b, 0)
@@ -64,12 +76,13 @@ class _PairResults:
 
 
 def replay(ctx: Context, frames, stamps, altitudes, K, orientation0, location0, Rbc=None, motion2D=False, gt_z=None,
-           chunk: int = 64):
-    """frames: list of H x W uint8 (already preprocessed: the node's get_image is out of scope); stamps [s] and altitudes [m]
-    per frame; orientation0 ({camera} -> {W}) and location0 as the node initialises them from the ground truth.
+           chunk: int = 64, prep=None):
+    """frames: list of H x W uint8 preprocessed frames, or - with prep, a visual_odometry_amd.prep.Prep - the raw BGR frames
+    of the camera topic, which then go through the node's get_image on the device; K is the camera matrix of the
+    preprocessed frames (after updateCameraMatrix); stamps [s] and altitudes [m] per frame; orientation0 ({camera} -> {W}) and location0 as the node initialises them from the ground truth.
     Returns one record per loop iteration (frames 1..N-1)."""
     Rbc = np.eye(3) if Rbc is None else np.asarray(Rbc, np.float64)
-    res = _PairResults(ctx, frames, K, chunk)
+    res = _PairResults(ctx, frames, K, chunk, prep)
     orientation, location = np.array(orientation0, np.float64), np.array(location0, np.float64)
     R, t, SF = np.eye(3), np.zeros(3), 1.0
     prev, prev_time = 0, stamps[0]
