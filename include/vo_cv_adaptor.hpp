@@ -1,7 +1,14 @@
-// vo_cv_adaptor.hpp -- the three reference signatures on top of libvo_mi355x.so, for a tree that has OpenCV.
-// Include this INSTEAD of the function bodies of include/visual_odometry/camera_utility.hpp:742-809, 633-685,
-// 288-351; src/visual_Odometry.cpp:296, 336, 384 then compile unchanged.  Not compiled in this repository
-// (OpenCV is not installed here); see INTEGRATION.md.
+// vo_cv_adaptor.hpp -- the reference's hot-path signatures on top of libvo_mi355x.so, for a tree that has OpenCV.
+//
+// Replaces, with identical signatures (reference include/visual_odometry/camera_utility.hpp):
+//     Mat  get_image(Mat current_img, int desired_width, int desired_height, Mat cameraMatrix, Mat distortionCoeff)   :147
+//     void opt_DetectFeatures(Mat img1, Mat img2, KpAsPoint2f_Match& kP_converted)                                     :742
+//     void optRelativePose(KpAsPoint2f_Match kP, Mat K, Mat& R, Mat& t, KpAsPoint2f_Match& inlier, bool& success)       :633
+//     Mat  triangPoints(vector<Point2f> inlier1, vector<Point2f> inlier2, Mat R, Mat t, Mat cameraMatrix)              :288
+// so that src/visual_Odometry.cpp:228, 290, 296, 336, 384 compile unchanged.  The match structure is a template
+// parameter: the node's own `KpAsPoint2f_Match` (:73-78, members Kpoints1, Kpoints2, match) is used as it is.
+// integration/ros/ shows the three-line change that switches the node over; tests/mock_cv holds the minimal cv:: types
+// this header is syntax-checked against in this repository (OpenCV is not installed here).
 #pragma once
 #include <opencv2/core.hpp>
 
@@ -14,70 +21,82 @@ inline vo::Frontend& frontend() {
     return f;
 }
 
-struct KpAsPoint2f_Match {  // camera_utility.hpp:73-78
-    std::vector<cv::Point2f> Kpoints1, Kpoints2;
-    std::vector<cv::DMatch> match;
-};
-
 inline vo::Image view(const cv::Mat& m) {
     CV_Assert(m.type() == CV_8UC1);
     return vo::Image{m.data, m.rows, m.cols, (size_t)m.step};
 }
 
-inline void opt_DetectFeatures(cv::Mat img1, cv::Mat img2, KpAsPoint2f_Match& out) {
-    vo::KpAsPoint2f_Match k;
-    frontend().opt_DetectFeatures(view(img1), view(img2), k);
-    out.Kpoints1.assign(reinterpret_cast<const cv::Point2f*>(k.Kpoints1.data()),
-                        reinterpret_cast<const cv::Point2f*>(k.Kpoints1.data()) + k.Kpoints1.size());
-    out.Kpoints2.assign(reinterpret_cast<const cv::Point2f*>(k.Kpoints2.data()),
-                        reinterpret_cast<const cv::Point2f*>(k.Kpoints2.data()) + k.Kpoints2.size());
+inline vo::Mat33 mat33(const cv::Mat& m) {
+    cv::Mat d;
+    m.convertTo(d, CV_64F);
+    CV_Assert(d.rows == 3 && d.cols == 3);
+    vo::Mat33 o;
+    for (int i = 0; i < 9; i++) o[i] = d.at<double>(i / 3, i % 3);
+    return o;
+}
+
+template <class P>
+inline std::vector<vo::Point2f> points(const std::vector<P>& v) {
+    std::vector<vo::Point2f> o(v.size());
+    for (size_t i = 0; i < v.size(); i++) o[i] = vo::Point2f{v[i].x, v[i].y};
+    return o;
+}
+
+template <class KP>
+inline void store(const vo::KpAsPoint2f_Match& k, KP& out) {
+    out.Kpoints1.clear();
+    out.Kpoints2.clear();
     out.match.clear();
+    for (const vo::Point2f& p : k.Kpoints1) out.Kpoints1.emplace_back(p.x, p.y);
+    for (const vo::Point2f& p : k.Kpoints2) out.Kpoints2.emplace_back(p.x, p.y);
     for (const vo_dmatch& m : k.match) out.match.emplace_back(m.queryIdx, m.trainIdx, m.imgIdx, m.distance);
 }
 
-inline void optRelativePose(KpAsPoint2f_Match kP, cv::Mat K, cv::Mat& R, cv::Mat& t, KpAsPoint2f_Match& inlier, bool& success) {
+inline cv::Mat get_image(cv::Mat current_img, int desired_width, int desired_height, cv::Mat cameraMatrix, cv::Mat distortionCoeff) {
+    CV_Assert(current_img.type() == CV_8UC3);
+    cv::Mat d;
+    distortionCoeff.convertTo(d, CV_64F);
+    std::array<double, 4> dist{0, 0, 0, 0};
+    for (int i = 0; i < 4 && i < (int)d.total(); i++) dist[i] = d.at<double>(i);
+    const std::vector<uint8_t> g = frontend().get_image(current_img.data, current_img.rows, current_img.cols, (size_t)current_img.step,
+                                                        desired_width, desired_height, mat33(cameraMatrix), dist);
+    return cv::Mat(desired_height, desired_width, CV_8UC1, const_cast<uint8_t*>(g.data())).clone();
+}
+
+template <class KP>
+inline void opt_DetectFeatures(cv::Mat img1, cv::Mat img2, KP& kP_converted) {
+    vo::KpAsPoint2f_Match k;
+    frontend().opt_DetectFeatures(view(img1), view(img2), k);
+    store(k, kP_converted);
+}
+
+template <class KP>
+inline void optRelativePose(KP kP_converted, cv::Mat cameraMatrix, cv::Mat& R, cv::Mat& t, KP& inlier_converted, bool& success) {
     vo::KpAsPoint2f_Match in, out;
-    in.Kpoints1.assign(reinterpret_cast<const vo::Point2f*>(kP.Kpoints1.data()),
-                       reinterpret_cast<const vo::Point2f*>(kP.Kpoints1.data()) + kP.Kpoints1.size());
-    in.Kpoints2.assign(reinterpret_cast<const vo::Point2f*>(kP.Kpoints2.data()),
-                       reinterpret_cast<const vo::Point2f*>(kP.Kpoints2.data()) + kP.Kpoints2.size());
-    vo::Mat33 Km, Rm;
+    in.Kpoints1 = points(kP_converted.Kpoints1);
+    in.Kpoints2 = points(kP_converted.Kpoints2);
+    vo::Mat33 Rm = mat33(R);
     vo::Vec3 tv;
-    cv::Mat Kd, Rd, td;
-    K.convertTo(Kd, CV_64F);
-    R.convertTo(Rd, CV_64F);
+    cv::Mat td;
     t.convertTo(td, CV_64F);
-    for (int i = 0; i < 9; i++) {
-        Km[i] = Kd.at<double>(i / 3, i % 3);
-        Rm[i] = Rd.at<double>(i / 3, i % 3);
-    }
     for (int i = 0; i < 3; i++) tv[i] = td.at<double>(i);
-    frontend().optRelativePose(in, Km, Rm, tv, out, success);
-    inlier.Kpoints1.assign(reinterpret_cast<const cv::Point2f*>(out.Kpoints1.data()),
-                           reinterpret_cast<const cv::Point2f*>(out.Kpoints1.data()) + out.Kpoints1.size());
-    inlier.Kpoints2.assign(reinterpret_cast<const cv::Point2f*>(out.Kpoints2.data()),
-                           reinterpret_cast<const cv::Point2f*>(out.Kpoints2.data()) + out.Kpoints2.size());
-    inlier.match.clear();
-    for (const vo_dmatch& m : out.match) inlier.match.emplace_back(m.queryIdx, m.trainIdx, m.imgIdx, m.distance);
+    frontend().optRelativePose(in, mat33(cameraMatrix), Rm, tv, out, success);
+    store(out, inlier_converted);
     if (success) {  // R, t are in/out: untouched unless success (camera_utility.hpp:673-679)
         R = cv::Mat(3, 3, CV_64F, Rm.data()).clone();
         t = cv::Mat(3, 1, CV_64F, tv.data()).clone();
     }
 }
 
-inline cv::Mat triangPoints(std::vector<cv::Point2f> inl1, std::vector<cv::Point2f> inl2, cv::Mat R, cv::Mat t, cv::Mat K) {
-    std::vector<vo::Point2f> a(reinterpret_cast<const vo::Point2f*>(inl1.data()), reinterpret_cast<const vo::Point2f*>(inl1.data()) + inl1.size());
-    std::vector<vo::Point2f> b(reinterpret_cast<const vo::Point2f*>(inl2.data()), reinterpret_cast<const vo::Point2f*>(inl2.data()) + inl2.size());
-    vo::Mat33 Km, Rm;
+template <class P>
+inline cv::Mat triangPoints(std::vector<P> inlier1, std::vector<P> inlier2, cv::Mat R, cv::Mat t, cv::Mat cameraMatrix) {
     vo::Vec3 tv;
-    for (int i = 0; i < 9; i++) {
-        Km[i] = K.at<double>(i / 3, i % 3);
-        Rm[i] = R.at<double>(i / 3, i % 3);
-    }
-    for (int i = 0; i < 3; i++) tv[i] = t.at<double>(i);
+    cv::Mat td;
+    t.convertTo(td, CV_64F);
+    for (int i = 0; i < 3; i++) tv[i] = td.at<double>(i);
     int m = 0;
-    std::vector<double> X = frontend().triangPoints(a, b, Rm, tv, Km, &m);
-    if (m == 0) return cv::Mat();  // caller checks .empty() (visual_Odometry.cpp:386)
+    std::vector<double> X = frontend().triangPoints(points(inlier1), points(inlier2), mat33(R), tv, mat33(cameraMatrix), &m);
+    if (m == 0) return cv::Mat();  // the caller checks .empty() (visual_Odometry.cpp:386)
     return cv::Mat(3, m, CV_64F, X.data()).clone();
 }
 

@@ -9,6 +9,7 @@
 #pragma once
 #include <array>
 #include <cstdint>
+#include <cstring>
 #include <stdexcept>
 #include <string>
 #include <vector>
@@ -43,7 +44,10 @@ class Frontend {
         if (st != VO_OK) throw std::runtime_error(std::string("vo_ctx_create: ") + vo_strerror(st) + " " + vo_last_hip_error());
         vo_ctx_get_params(ctx_, &prm_);
     }
-    ~Frontend() { vo_ctx_destroy(ctx_); }
+    ~Frontend() {
+        if (prep_) vo_prep_destroy(prep_);
+        vo_ctx_destroy(ctx_);
+    }
     Frontend(const Frontend&) = delete;
     Frontend& operator=(const Frontend&) = delete;
 
@@ -137,6 +141,29 @@ class Frontend {
         return a;
     }
 
+    // Mat get_image(Mat current_img, int desired_width, int desired_height, Mat cameraMatrix, Mat distortionCoeff)   :147
+    // bgr: CV_8UC3 view (data, rows, cols, step); K: camera matrix of the RESIZED frames (the node calls updateCameraMatrix
+    // before, visual_Odometry.cpp:225); dist: k1 k2 p1 p2.  Returns the desired_height x desired_width gray frame, row-major.
+    // The maps and tables of the camera are built on first use and kept (one camera per node).
+    std::vector<uint8_t> get_image(const uint8_t* bgr, int rows, int cols, size_t step, int desired_width, int desired_height,
+                                   const Mat33& K, const std::array<double, 4>& dist) {
+        vo_prep_params p{};
+        p.src_rows = rows, p.src_cols = cols, p.dst_rows = desired_height, p.dst_cols = desired_width;
+        for (int i = 0; i < 9; i++) p.K[i] = K[i];
+        for (int i = 0; i < 4; i++) p.dist[i] = dist[i];
+        p.clip_limit = 16.0;  // CLIP_LIMIT, camera_utility.hpp:10
+        p.tiles_x = p.tiles_y = 8;
+        if (!prep_ || std::memcmp(&p, &prep_params_, sizeof(p)) != 0) {
+            if (prep_) vo_prep_destroy(prep_);
+            prep_ = nullptr;
+            check(vo_prep_create(ctx_, &p, &prep_), "vo_prep_create");
+            prep_params_ = p;
+        }
+        std::vector<uint8_t> gray((size_t)desired_height * desired_width);
+        check(vo_prep_run(prep_, bgr, step, gray.data(), (size_t)desired_width), "vo_prep_run");
+        return gray;
+    }
+
     vo_ctx* handle() { return ctx_; }
 
    private:
@@ -145,6 +172,8 @@ class Frontend {
     }
     vo_ctx* ctx_ = nullptr;
     vo_params prm_{};
+    vo_prep* prep_ = nullptr;
+    vo_prep_params prep_params_{};
 };
 
 }  // namespace vo

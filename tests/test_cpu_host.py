@@ -117,3 +117,16 @@ def test_result_gather_two_ranks_gloo(tmp_path):
                               stderr=subprocess.STDOUT) for r in range(2)]
     outs = [p.communicate(timeout=180)[0].decode() for p in procs]
     assert all(p.returncode == 0 for p in procs), outs
+
+
+def test_cv_adaptor_and_ros_switch_headers_compile(tmp_path):
+    """N3: include/vo_cv_adaptor.hpp + integration/ros/vo_mi355x_switch_*.hpp, used the way the node would use them
+    (tests/cv_adaptor_check.cpp), compile and link against the library with the mock cv:: types of tests/mock_cv."""
+    import subprocess
+
+    exe = str(tmp_path / "cv_adaptor_check")
+    lib_dir = os.path.join(ROOT, "visual_odometry_amd")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-Werror", "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(ROOT, "tests", "mock_cv"),
+                           "-I" + os.path.join(ROOT, "integration", "ros"), os.path.join(ROOT, "tests", "cv_adaptor_check.cpp"), "-o", exe,
+                           "-L" + lib_dir, "-lvo_mi355x", "-Wl,-rpath," + lib_dir])
+    assert subprocess.call([exe]) == 0  # without arguments: no GPU call, just proves the link

@@ -230,3 +230,17 @@ def test_bag_to_poses_end_to_end(ctx, tmp_path):
             assert a["SF"] == b["SF"]
     Rgt, tgt, base = sc.relative(0, 1)
     assert _angle(recs[0]["R"], Rgt) < 1.0
+
+
+def test_cv_adaptor_runs_the_node_call_sequence():
+    """N3: the switch headers + cv::Mat adaptor (mock cv types) run get_image -> opt_DetectFeatures -> optRelativePose ->
+    triangPoints as src/visual_Odometry.cpp:228-384 calls them.  The binary is built by __graft_entry__.build()."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "cv_adaptor_check")
+    if not os.path.exists(exe):
+        pytest.fail("examples/cv_adaptor_check missing: run __graft_entry__.build()")
+    out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "success 1" in out.stdout, out.stdout
