@@ -219,8 +219,11 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
     DetectTables t;
     vo_build_detect_tables(t, 0);
     int st = vo_upload_detect_tables(t);
+    if (st == VO_OK && (hipMalloc((void**)&ctx->d_redo_cnt, sizeof(int)) != hipSuccess || hipMemset(ctx->d_redo_cnt, 0, sizeof(int)) != hipSuccess))
+        st = VO_ERR_HIP;
     if (st == VO_OK) st = vo_geometry_init(ctx);
     if (st != VO_OK) {
+        if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
         hipStreamDestroy(ctx->stream);
         delete ctx;
         return st;
@@ -237,6 +240,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     vo_frameset_free(ctx->fs);
     vo_pairset_free(ctx->ps);
     if (ctx->d_tmp) hipFree(ctx->d_tmp);
+    if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -340,7 +344,6 @@ int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp)
     VO_TRY(dalloc(ps.cand_val, pk * 32));
     VO_TRY(dalloc(ps.cand_idx, pk * 32));
     VO_TRY(dalloc(ps.redo_list, pk));
-    VO_TRY(dalloc(ps.redo_cnt, (size_t)1));
     VO_TRY(dalloc(ps.knn_idx, pk * 2));
     VO_TRY(dalloc(ps.knn_dist, pk * 2));
     VO_TRY(dalloc(ps.p1, pm * 2));
@@ -376,7 +379,6 @@ void vo_pairset_free(PairSet& ps) {
     dfree(ps.cand_val);
     dfree(ps.cand_idx);
     dfree(ps.redo_list);
-    dfree(ps.redo_cnt);
     dfree(ps.knn_idx);
     dfree(ps.knn_dist);
     dfree(ps.p1);
@@ -904,10 +906,10 @@ extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2
 extern "C" int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes) {
     if (!ctx || !dst) return VO_ERR_INVALID_ARG;
     if (what == 4) {  // queries of the last matcher launch (any batch of this context) that took the exact scan
-        if (!ctx->last_redo_cnt || bytes < sizeof(int)) return VO_ERR_INVALID_ARG;
+        if (bytes < sizeof(int)) return VO_ERR_INVALID_ARG;
         VO_HIP(hipSetDevice(ctx->device));
         VO_HIP(hipStreamSynchronize(ctx->stream));
-        VO_HIP(hipMemcpy(dst, ctx->last_redo_cnt, sizeof(int), hipMemcpyDeviceToHost));
+        VO_HIP(hipMemcpy(dst, ctx->d_redo_cnt, sizeof(int), hipMemcpyDeviceToHost));
         return VO_OK;
     }
     if (!ctx->ps.st) return VO_ERR_INVALID_ARG;

@@ -153,7 +153,6 @@ struct PairSet {
     int* cand_idx = nullptr;
     int* knn_idx = nullptr;     // [P][kp_cap][2]
     int* redo_list = nullptr;   // [P*kp_cap] queries whose shortlist could not be certified (pair*cap + q)
-    int* redo_cnt = nullptr;    // [1]
     float* knn_dist = nullptr;  // [P][kp_cap][2]
     float* p1 = nullptr;        // [P][match_cap][2]
     float* p2 = nullptr;
@@ -184,7 +183,8 @@ struct vo_ctx {
     bool profiling = false;
     int force_seq_describe = 0;     // vo_debug_set key 0
     int force_exact_match = 0;      // vo_debug_set key 1: no shortlist is certified, every query takes the exact scan
-    const int* last_redo_cnt = nullptr;  // device counter of the last matcher launch (vo_debug_fetch 4)
+    int* d_redo_cnt = nullptr;      // [1] length of the matcher's redo list; one per context: every launch of a context is
+                                    // on its one in-order stream (vo_debug_fetch 4 reads the last launch's value)
     StageTimer timers[ST_COUNT];
     // lazily sized scratch for the single-call entry points
     FrameSet fs;

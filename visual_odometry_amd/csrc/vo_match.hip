@@ -552,7 +552,7 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
     {
         StageScope sc(ctx, ST_MATCH_PREP);
         VO_HIP(hipMemsetAsync(fs.nmax, 0, (size_t)fs.F * sizeof(int), ctx->stream));
-        VO_HIP(hipMemsetAsync(ps.redo_cnt, 0, sizeof(int), ctx->stream));
+        VO_HIP(hipMemsetAsync(ctx->d_redo_cnt, 0, sizeof(int), ctx->stream));
         hipLaunchKernelGGL(k_match_prep, dim3(cap / 32, fs.F), dim3(64), 0, ctx->stream, fs.desc, fs.cnt, cap,
                            reinterpret_cast<float4*>(fs.descT), fs.nrm, fs.nmax);
         VO_HIP(hipGetLastError());
@@ -572,11 +572,10 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
     {
         StageScope sc(ctx, ST_MATCH_SELECT);
         const float cert_scale = ctx->force_exact_match ? 1e30f : 1.f;
-        ctx->last_redo_cnt = ps.redo_cnt;
         hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.cand_idx,
-                           ps.cand_val, fs.nmax, 2 * ksplit, cert_scale, ps.knn_idx, ps.knn_dist, ps.redo_list, ps.redo_cnt);
+                           ps.cand_val, fs.nmax, 2 * ksplit, cert_scale, ps.knn_idx, ps.knn_dist, ps.redo_list, ctx->d_redo_cnt);
         hipLaunchKernelGGL(k_match_exact, dim3(1024), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.redo_list,
-                           ps.redo_cnt, ps.knn_idx, ps.knn_dist);
+                           ctx->d_redo_cnt, ps.knn_idx, ps.knn_dist);
         if (filter) {
             const vo_params& p = ctx->prm;
             hipLaunchKernelGGL(k_match_filter, dim3(P), dim3(1024), 0, ctx->stream, fs.kp, fs.cnt, cap, ps.frames,
