@@ -149,3 +149,30 @@ def test_describe_sequential_walk_matches_tiled(ctx):
     assert len(kp_a) == len(kp_b) > 100
     assert np.array_equal(kp_a["angle"], kp_b["angle"])
     assert np.array_equal(d_a, d_b)
+
+
+def test_descriptor_cells_spanning_many_binades(ctx):
+    """Isolated blobs on a perfectly flat background, plus one-grey-level steps: descriptor cells that are exactly zero,
+    cells that hold a single tiny weighted gradient and cells with full-contrast structure in the same window.  The
+    normalisation's tree sum is only used when it provably equals the reference's sequential double sum (cell energies
+    within 23 binades); these windows take the sequential branch as well."""
+    img = np.full((480, 640), 120, np.uint8)
+    yy, xx = np.mgrid[0:480, 0:640]
+    rng = np.random.default_rng(7)
+    f = img.astype(np.float64)
+    for _ in range(40):
+        cy, cx = rng.integers(40, 440), rng.integers(40, 600)
+        sg = rng.uniform(2.0, 7.0)
+        f += rng.choice([-100.0, 110.0]) * np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * sg * sg)) * (np.hypot(yy - cy, xx - cx) < 3 * sg)
+    img = np.clip(np.rint(f), 0, 255).astype(np.uint8)
+    img[:, 300:] += 1  # faint steps through many windows
+    img[200:, :] += 1
+    k, d = ctx.detect_describe(img)
+    rk, rd = O.detect_describe(img)
+    _assert_kps_equal(k, rk)
+    assert len(k) > 30
+    assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+    energy = (rd.reshape(len(rd), 16, 4) ** 2)
+    nz = np.where(energy > 0, energy, np.nan)
+    spread = np.log2(np.nanmax(nz.reshape(len(rd), -1), axis=1) / np.nanmin(nz.reshape(len(rd), -1), axis=1))
+    assert (spread > 23).sum() >= 3 and (spread <= 23).sum() >= 3, (np.sort(spread)[-5:], len(k))  # both branches were taken

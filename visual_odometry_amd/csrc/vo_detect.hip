@@ -1058,27 +1058,43 @@ __device__ __forceinline__ void describe_patch_to_vec(int tid, int NT, const uin
     }
     __syncthreads();
     if (tid < 64) {
-        // lane = cell*4 + q : 25 sequential float adds per lane, the order of the reference loops
+        // lane = cell*4 + q : 25 sequential float adds per lane, the order of the reference loops.  q picks the plane
+        // (dx / dy) and whether the sign bit is cleared (|dx|, |dy|): one LDS read, one AND, one add per element.
         const int cell = lane >> 2, q = lane & 3;
         const int ci = cell >> 2, cj = cell & 3;
+        const float* plane = (q & 1) ? s_DY : s_DX;
+        const uint32_t keep = q >= 2 ? 0x7fffffffu : 0xffffffffu;
         float acc = 0.f;
-        for (int y = ci * 5; y < ci * 5 + 5; y++)
-            for (int x = cj * 5; x < cj * 5 + 5; x++) {
-                const float tx = s_DX[y * kPatch + x], ty = s_DY[y * kPatch + x];
-                const float v = q == 0 ? tx : (q == 1 ? ty : (q == 2 ? fabsf(tx) : fabsf(ty)));
-                acc += v;
+#pragma unroll
+        for (int y = 0; y < 5; y++)
+#pragma unroll
+            for (int x = 0; x < 5; x++) acc += __uint_as_float(__float_as_uint(plane[(ci * 5 + y) * kPatch + cj * 5 + x]) & keep);
+        // square_mag = sum over kk of (double)(v*v), added in index order by the reference.  Every term is a float; when the
+        // exponents of the non-zero terms span at most 23 binades, every partial sum of them - in ANY order - is a multiple of
+        // 2^(emin-150) below 2^(emax-120) and fits a double's 53 bits, so a tree sum gives the sequential result bit for bit.
+        // Otherwise (a cell sum ~3000 times smaller than another) the lanes walk the 64 values in order.
+        const float t = acc * acc;
+        const int e = (__float_as_int(t) >> 23) & 0xff;
+        typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+        u16x2 span = {(unsigned short)(t != 0.f ? e : 0), (unsigned short)(t != 0.f ? 255 - e : 0)};  // max exponent | 255 - min exponent
+        double square_mag = (double)t;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            const uint32_t o = (uint32_t)__shfl_xor((int)__builtin_bit_cast(uint32_t, span), m, 64);
+            span = __builtin_elementwise_max(span, __builtin_bit_cast(u16x2, o));
+            square_mag += __shfl_xor(square_mag, m, 64);
+        }
+        if ((int)span.x - (255 - (int)span.y) > 23) {  // wave-uniform
+            s_vec[lane] = acc;
+            wave_sync_lds();
+            square_mag = 0;
+            for (int kk = 0; kk < 64; kk++) {
+                const float v = s_vec[kk];
+                square_mag += (double)(v * v);
             }
-        s_vec[lane] = acc;
-    }
-    __syncthreads();
-    if (tid < 64) {
-        double square_mag = 0;
-        for (int kk = 0; kk < 64; kk++) {
-            const float v = s_vec[kk];
-            square_mag += (double)(v * v);
         }
         const float nscale = (float)(1. / (sqrt(square_mag) + (double)FLT_EPSILON));
-        desc_out[lane] = s_vec[lane] * nscale;
+        desc_out[lane] = acc * nscale;
     }
 }
 
