@@ -150,6 +150,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.descT, (size_t)F * cap * 72));  // 9 slabs of 32 B per row
     VO_TRY(dalloc(fs.nrm, (size_t)F * cap));
     VO_TRY(dalloc(fs.nmax, (size_t)F));
+    VO_TRY(dalloc(fs.dir_sc, (size_t)F * cap));
     VO_TRY(dalloc(fs.cnt, (size_t)F));
     VO_TRY(dalloc(fs.cls_list, (size_t)5 * F * cap));
     VO_TRY(dalloc(fs.cls_cnt, (size_t)kClsCntInts));
@@ -171,6 +172,7 @@ void vo_frameset_free(FrameSet& fs) {
     dfree(fs.descT);
     dfree(fs.nrm);
     dfree(fs.nmax);
+    dfree(fs.dir_sc);
     dfree(fs.cnt);
     dfree(fs.cls_list);
     dfree(fs.cls_cnt);
@@ -221,9 +223,12 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
     int st = vo_upload_detect_tables(t);
     if (st == VO_OK && (hipMalloc((void**)&ctx->d_redo_cnt, sizeof(int)) != hipSuccess || hipMemset(ctx->d_redo_cnt, 0, sizeof(int)) != hipSuccess))
         st = VO_ERR_HIP;
+    if (st == VO_OK) st = vo_build_window_tables(ctx);
     if (st == VO_OK) st = vo_geometry_init(ctx);
     if (st != VO_OK) {
         if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
+        if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
+        if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
         hipStreamDestroy(ctx->stream);
         delete ctx;
         return st;
@@ -241,6 +246,8 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     vo_pairset_free(ctx->ps);
     if (ctx->d_tmp) hipFree(ctx->d_tmp);
     if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
+    if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
+    if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }

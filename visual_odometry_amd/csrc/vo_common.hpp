@@ -136,6 +136,7 @@ struct FrameSet {
     float* descT = nullptr;         // [F][cap/32][9][64] x 16 B: MFMA operand layout (bf16 high parts, low parts, norm term)
     float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
     int* nmax = nullptr;            // [F] bits of the largest ||b||^2 of the frame
+    float2* dir_sc = nullptr;       // [F][cap] (sin, cos) of every keypoint's descriptor direction
     FrameCounters* cnt = nullptr;   // [F]
     int* cls_list = nullptr;        // [5][F*cap] keypoints (frame*cap + k) of each descriptor window class; list 4 = sequential-walk fallback
     int* cls_cnt = nullptr;         // [kClsCntInts] list lengths [0..4]; work-queue tickets [8 + 8*cls + segment]
@@ -179,6 +180,8 @@ struct vo_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     DetectTables* d_tables = nullptr;
+    void* d_win_cell = nullptr;     // INTER_AREA decimation tables of every window size (vo_detect.hip: CellTab [769][21 + 1])
+    void* d_win_pix = nullptr;      // PixTab [769][768]
     uint32_t* d_rng_raw = nullptr;  // unused placeholder (rng stream is generated on device)
     bool profiling = false;
     int force_seq_describe = 0;     // vo_debug_set key 0
@@ -250,4 +253,5 @@ int vo_enqueue_triangulate(vo_ctx* ctx, const double* d_P01, const float* d_p1, 
 float vo_thr_sq(double thr_px, const double K[9]);
 int vo_enqueue_normalise(vo_ctx* ctx, PairSet& ps, double thr_px);
 int vo_upload_detect_tables(const DetectTables& t);
+int vo_build_window_tables(vo_ctx* ctx);
 int vo_geometry_init(vo_ctx* ctx);

@@ -1357,6 +1357,32 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
     }
 }
 
+// The decimation tables depend on the window size only: built once per context for every size the tiled kernels see
+// (k_build_win_tables, the same device functions as the sequential kernel uses), then loaded per keypoint instead of being
+// recomputed (22 double divisions + a 4-cell search per source pixel, ~200-1400 wavefront instructions per keypoint).
+constexpr int kWinTabPitch = kBigWin;  // PixTab entries per window size
+__global__ __launch_bounds__(256) void k_build_win_tables(CellTab* __restrict__ g_cell, PixTab* __restrict__ g_pix) {
+    __shared__ CellTab s_cell[kPatch + 1];
+    __shared__ PixTab s_pix[kBigWin];
+    const int win = blockIdx.x + 1, tid = threadIdx.x;
+    const double scale = (double)win / (kPatch + 1);
+    if (tid <= kPatch) describe_cell_tab(tid, win, scale, s_cell);
+    __syncthreads();
+    describe_pix_tab(tid, 256, win, scale, s_cell, s_pix);
+    __syncthreads();
+    if (tid <= kPatch) g_cell[(size_t)win * (kPatch + 1) + tid] = s_cell[tid];
+    for (int j = tid; j < win; j += 256) g_pix[(size_t)win * kWinTabPitch + j] = s_pix[j];
+}
+
+int vo_build_window_tables(vo_ctx* ctx) {
+    VO_HIP(hipMalloc(&ctx->d_win_cell, (size_t)(kBigWin + 1) * (kPatch + 1) * sizeof(CellTab)));
+    VO_HIP(hipMalloc(&ctx->d_win_pix, (size_t)(kBigWin + 1) * kWinTabPitch * sizeof(PixTab)));
+    hipLaunchKernelGGL(k_build_win_tables, dim3(kBigWin), dim3(256), 0, ctx->stream, (CellTab*)ctx->d_win_cell, (PixTab*)ctx->d_win_pix);
+    VO_HIP(hipGetLastError());
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
 // WHI: largest window of the class; NW wavefronts per keypoint; a gather covers RB rows x 64/RB columns; UMAX gathers in
 // flight per lane; a strip is G groups of RB rows per wavefront (sampled back to back, then one row pass and one fold);
 // CH work-queue tickets per atomic.
@@ -1367,7 +1393,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                                                             int W, vo_keypoint* __restrict__ kp_base,
                                                             float* __restrict__ desc_base, int cap,
                                                             const int* __restrict__ list, int* __restrict__ cls_cnt, int cls,
-                                                            int* __restrict__ seq_list, int force_seq) {
+                                                            int* __restrict__ seq_list, int force_seq,
+                                                            const CellTab* __restrict__ g_cell, const PixTab* __restrict__ g_pix,
+                                                            const float2* __restrict__ dir_sc) {
     constexpr int NT = NW * 64;
     constexpr int CB = 64 / RB;                    // columns of one gather
     constexpr int WR = RB * G;                     // rows of one wavefront in a strip
@@ -1429,6 +1457,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
             s_q[3] = __float_as_int(kq->y);
             s_q[4] = __float_as_int(kq->size);
             s_q[5] = __float_as_int(kq->angle);
+            const float2 d = dir_sc[cd];
+            s_q[6] = __float_as_int(d.x);
+            s_q[7] = __float_as_int(d.y);
         }
     }
     for (;;) {
@@ -1437,7 +1468,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         if (item >= n_items) break;
         const int code = s_q[1];
         const float cx = __int_as_float(s_q[2]), cy = __int_as_float(s_q[3]), size = __int_as_float(s_q[4]);
-        const float descriptor_dir = __int_as_float(s_q[5]);  // k_orientation
+        const float sin_dir = -__int_as_float(s_q[6]), cos_dir = __int_as_float(s_q[7]);  // k_classify_count: sin, cos of the angle
         const int frame = code / cap, k = code - frame * cap;
         int n_item = 0, n_code = 0;
         if (tid == 0) n_item = draw();  // look-ahead stage 1: ticket
@@ -1448,13 +1479,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         const double scale = (double)win / (kPatch + 1);
         const int iscale = d_cvRoundD(scale);
         const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
-        if (!area_fast && tid <= kPatch) describe_cell_tab(tid, win, scale, s_cell);
-        __syncthreads();
+        // the window size's decimation tables (k_build_win_tables)
+        if (!area_fast) {
+            if (tid <= kPatch) s_cell[tid] = g_cell[(size_t)win * (kPatch + 1) + tid];
+            for (int j = tid; j < win; j += NT) s_pix[j] = g_pix[(size_t)win * kWinTabPitch + j];
+        }
         if (tid == 0) n_code = *(volatile const int*)&list[min(n_item, n_items - 1)];  // look-ahead stage 2: list entry
-        const float dir = descriptor_dir * (float)(3.1415926535897932384626433832795 / 180);
-        const float2 sc2 = direction_sincos(dir);
-        const float sin_dir = -sc2.x;
-        const float cos_dir = sc2.y;
         const float win_offset = -(float)(win - 1) / 2;
         const int ncols1 = W - 1, nrows1 = H - 1;
         const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
@@ -1472,7 +1502,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                 v += inc;
             }
         }
-        if (!area_fast) describe_pix_tab(tid, NT, win, scale, s_cell, s_pix);
         __syncthreads();
 
         lds_u8* wbase = (lds_u8*)s_win + wave * (WR * kPitch);
@@ -1627,6 +1656,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         if (tid == 0) {  // look-ahead stage 3: the next keypoint's record (every thread has read s_q: barriers passed)
             const volatile float* kq = reinterpret_cast<const volatile float*>(kp_base + n_code);
             const float nx = kq[0], ny = kq[1], nsz = kq[2], nan_ = kq[3];
+            const volatile float* dq = reinterpret_cast<const volatile float*>(dir_sc + n_code);
+            const float nsin = dq[0], ncos = dq[1];
+            s_q[6] = __float_as_int(nsin);
+            s_q[7] = __float_as_int(ncos);
             s_q[0] = n_item;
             s_q[1] = n_code;
             s_q[2] = __float_as_int(nx);
@@ -1659,13 +1692,16 @@ __device__ __forceinline__ int classify_key(const vo_keypoint& kp, int frame, in
 
 __global__ __launch_bounds__(256) void k_classify_count(const vo_keypoint* __restrict__ kp_base, int cap,
                                                         const FrameCounters* __restrict__ cnt, int W, int nbins, int nkeys,
-                                                        int* __restrict__ hist) {
+                                                        int* __restrict__ hist, float2* __restrict__ dir_sc) {
     const int frame = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= min(cnt[frame].n_raw, cap)) return;
     int cls;
-    const int key = classify_key(kp_base[(size_t)frame * cap + k], frame, W, nbins, &cls);
+    const vo_keypoint kp = kp_base[(size_t)frame * cap + k];
+    const int key = classify_key(kp, frame, W, nbins, &cls);
     atomicAdd(&hist[cls * nkeys + key], 1);
+    // sin / cos of the descriptor direction, one keypoint per LANE here instead of one per wavefront in the descriptor kernels
+    dir_sc[(size_t)frame * cap + k] = direction_sincos(kp.angle * (float)(3.1415926535897932384626433832795 / 180));
 }
 
 // one workgroup per class: exclusive scan of the histogram in place (it becomes the scatter cursor), total -> cls_cnt
@@ -1782,7 +1818,7 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
                 const int nbins = fs.nbins(), nkeys = fs.F * nbins;
                 const dim3 gk((fs.cap + 255) / 256, fs.F);
                 hipLaunchKernelGGL(k_classify_count, gk, dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt, fs.W, nbins, nkeys,
-                                   fs.cls_hist);
+                                   fs.cls_hist, fs.dir_sc);
                 hipLaunchKernelGGL(k_classify_scan, dim3(4), dim3(1024), 0, ctx->stream, nkeys, fs.cls_hist, fs.cls_cnt);
                 hipLaunchKernelGGL(k_classify_scatter, gk, dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt, fs.W, nbins, nkeys,
                                    fs.cls_hist, fs.cls_list, ls);
@@ -1794,7 +1830,8 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         StageScope sc(ctx, STAGE);                                                                                                 \
         hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB, UMAX, G, CH>), dim3(GRID), dim3((NW) * 64), 0, ctx->stream, fs.img,          \
                            fs.img_stride(), fs.quad, fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap,                         \
-                           fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe); \
+                           fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe, \
+                           (const CellTab*)ctx->d_win_cell, (const PixTab*)ctx->d_win_pix, fs.dir_sc);                               \
     }
             // heaviest class first so that its long keypoints overlap the many short ones that follow
             LAUNCH_TILED(ST_DESC_W768, kBigWin, 4, 8, 8, 1, 1, 3, 768);
