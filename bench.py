@@ -134,6 +134,23 @@ def main():
     _ = [last.get(i) for i in range(args.batch)]
     barrier()
     pcie_rate = args.batch * h2d_steps * world / (time.perf_counter() - th)
+    # the same two batches, frames resident: the latency-bound kernels of one (RANSAC, sort, pose: ~2 ms of single wavefronts)
+    # run under the VALU-bound kernels of the other.  Reported beside `value` (whose kernels run alone, so that the per-kernel
+    # durations behind `roofline` mean something).
+    for b2 in duo:
+        b2.run()
+    for b2 in duo:
+        b2.sync()
+    barrier()
+    t2 = time.perf_counter()
+    duo_steps = 4
+    for _ in range(duo_steps):
+        for b2 in duo:
+            b2.run()
+    for b2 in duo:
+        b2.sync()
+    barrier()
+    duo_rate = 2 * args.batch * duo_steps * world / (time.perf_counter() - t2)
     batch_b.close()
     ctx_b.close()
 
@@ -287,6 +304,8 @@ def main():
                        "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
             "pcie_inclusive": {"value": round(pcie_rate, 2), "unit": "frame-pairs/s",
                                "note": "both frames of every pair uploaded from host memory every step (pinned staging, two alternating batches), result records read back"},
+            "two_batches_in_flight": {"value": round(duo_rate, 2), "unit": "frame-pairs/s",
+                                      "note": "two resident batches on two contexts (two HIP streams) alternating; same work per pair as `value`"},
             "consecutive_frames": {"value": round(seq_rate, 2), "unit": "frame-pairs/s",
                                    "note": "sequence batch: batch + 1 frames detected once each, pair p = (frame p, frame p + 1); not the headline workload"},
             "roofline": roofline,
