@@ -183,7 +183,7 @@ def main():
     nprof = 3
     for _ in range(nprof):
         batch.run()
-    batch.sync()
+        batch.sync()  # one run at a time: no geometry-stream overlap inside the per-kernel durations
     prof = ctx.profile()
     ctx.profile_enable(False)
     import ctypes as C

@@ -244,3 +244,42 @@ def test_cv_adaptor_runs_the_node_call_sequence():
     out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "success 1" in out.stdout, out.stdout
+
+
+def test_back_to_back_runs_with_new_inputs_in_between(ctx):
+    """The geometry of run i works on the geometry stream while the main stream already detects run i + 1: new frames and
+    new K written between two runs WITHOUT a sync in between must not disturb either run."""
+    A = [synth.blob_scene(480, 640, synth.K_PARETE, 700, 21), synth.blob_scene(480, 640, synth.K_PARETE, 500, 22)]
+    Bs = [synth.blob_scene(480, 640, synth.K_PARETE * np.array([[1.1], [1.1], [1.0]]), 600, 23), synth.blob_scene(480, 640, synth.K_PARETE, 800, 24)]
+
+    def fields(b, i):
+        o = b.get(i)
+        return (o.status, o.n_kp1, o.n_kp2, o.n_match, o.n_inl, o.n_good, o.n_world, o.success, o.iters, tuple(o.E), tuple(o.R), tuple(o.t))
+
+    ref = {}
+    for name, scenes in (("A", A), ("B", Bs)):
+        r = Batch(ctx, 2, 480, 640)
+        for i, sc in enumerate(scenes):
+            r.set_pair(i, sc.img1, sc.img2, sc.K)
+        r.run()
+        r.sync()
+        ref[name] = [(fields(r, i), [x.copy() for x in r.get_points(i)]) for i in range(2)]
+        r.close()
+    b = Batch(ctx, 2, 480, 640)
+    for i, sc in enumerate(A):
+        b.set_pair(i, sc.img1, sc.img2, sc.K)
+    b.run()
+    for i, sc in enumerate(Bs):  # no sync: run A's geometry may still be in flight
+        b.set_pair(i, sc.img1, sc.img2, sc.K)
+    b.run()
+    b.run()  # and once more on the same inputs
+    b.sync()
+    for i in range(2):
+        assert fields(b, i) == ref["B"][i][0]
+        for x, y in zip(b.get_points(i), ref["B"][i][1]):
+            assert np.array_equal(x, y)
+    for i, sc in enumerate(A):
+        b.set_pair(i, sc.img1, sc.img2, sc.K)
+    b.run()
+    assert fields(b, 0) == ref["A"][0][0] and fields(b, 1) == ref["A"][1][0]  # get without an explicit sync
+    b.close()

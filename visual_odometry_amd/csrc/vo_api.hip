@@ -214,7 +214,9 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
     vo_ctx* ctx = new vo_ctx();
     ctx->prm = p;
     ctx->device = hip_device;
-    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_geo, hipStreamNonBlocking) != hipSuccess) {
+        if (ctx->stream) hipStreamDestroy(ctx->stream);
         delete ctx;
         return VO_ERR_HIP;
     }
@@ -229,6 +231,7 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
         if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
         if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
+        hipStreamDestroy(ctx->stream_geo);
         hipStreamDestroy(ctx->stream);
         delete ctx;
         return st;
@@ -241,6 +244,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
+    hipStreamSynchronize(ctx->stream_geo);
     resolve_timers(ctx);
     vo_frameset_free(ctx->fs);
     vo_pairset_free(ctx->ps);
@@ -248,6 +252,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
     if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
     if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
+    hipStreamDestroy(ctx->stream_geo);
     hipStreamDestroy(ctx->stream);
     delete ctx;
 }
@@ -718,7 +723,9 @@ static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq
         return st;
     }
     if (hipHostMalloc((void**)&b->h_stage, (size_t)n_frames * rows * cols, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_match, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&b->ev_geo, hipEventDisableTiming) != hipSuccess) {
         vo_set_hip_error("hipHostMalloc/hipEventCreate", hipGetLastError(), __FILE__, __LINE__);
         vo_batch_destroy(b);
         return VO_ERR_HIP;
@@ -783,10 +790,13 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
     if (!b) return;
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
+    hipStreamSynchronize(b->ctx->stream_geo);
     vo_frameset_free(b->fs);
     vo_pairset_free(b->ps);
     if (b->h_stage) hipHostFree(b->h_stage);
     if (b->ev_upload) hipEventDestroy(b->ev_upload);
+    if (b->ev_match) hipEventDestroy(b->ev_match);
+    if (b->ev_geo) hipEventDestroy(b->ev_geo);
     delete b;
 }
 
@@ -819,6 +829,13 @@ extern "C" int vo_batch_run(vo_batch* b) {
         b->upload_pending = true;
     }
     VO_TRY(reset_counters(ctx, b->fs));
+    // The geometry of the previous run may still be working on this batch's pair buffers on the geometry stream: detection
+    // and description (frame buffers only) start right away, everything that writes pair buffers waits for it.
+    bool waited_geo = !b->geo_pending;
+    if (!waited_geo && (b->frames_dirty || b->state_dirty)) {
+        VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_geo, 0));
+        waited_geo = true;
+    }
     if (b->frames_dirty) {
         VO_HIP(hipMemcpyAsync(b->ps.frames, b->h_frames.data(), b->h_frames.size() * sizeof(int2), hipMemcpyHostToDevice,
                               ctx->stream));
@@ -831,14 +848,28 @@ extern "C" int vo_batch_run(vo_batch* b) {
         b->state_dirty = false;
     }
     VO_TRY(vo_enqueue_detect(ctx, b->fs, true));
+    if (!waited_geo) VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_geo, 0));
     VO_TRY(vo_enqueue_match(ctx, b->fs, b->ps, true));
+    // RANSAC, pose and triangulation are a few single-wavefront kernels (~1.6 ms of mostly idle GPU per step): they go to the
+    // geometry stream, where they run under the detection of whatever the main stream does next
+    VO_HIP(hipEventRecord(b->ev_match, ctx->stream));
+    VO_HIP(hipStreamWaitEvent(ctx->stream_geo, b->ev_match, 0));
     GeoOptions o;
     o.prob = ctx->prm.ransac_prob;
     o.thr_px = ctx->prm.ransac_threshold;
     o.max_iters = ctx->prm.ransac_max_iters;
     o.seed = ctx->prm.ransac_seed;
     o.dist_thresh = ctx->prm.distance_threshold;
-    VO_TRY(vo_enqueue_geometry(ctx, b->ps, o));
+    int st_geo;
+    {
+        hipStream_t main_stream = ctx->stream;
+        ctx->stream = ctx->stream_geo;  // the launchers and stage timers of vo_geometry.hip use ctx->stream
+        st_geo = vo_enqueue_geometry(ctx, b->ps, o);
+        ctx->stream = main_stream;
+    }
+    VO_TRY(st_geo);
+    VO_HIP(hipEventRecord(b->ev_geo, ctx->stream_geo));
+    b->geo_pending = true;
     b->fetched = false;
     return VO_OK;
 }
@@ -847,12 +878,14 @@ extern "C" int vo_batch_sync(vo_batch* b) {
     if (!b) return VO_ERR_INVALID_ARG;
     VO_HIP(hipSetDevice(b->ctx->device));
     VO_HIP(hipStreamSynchronize(b->ctx->stream));
+    if (b->geo_pending) VO_HIP(hipEventSynchronize(b->ev_geo));
     return VO_OK;
 }
 
 static int batch_fetch(vo_batch* b) {
     if (b->fetched) return VO_OK;
     vo_ctx* ctx = b->ctx;
+    if (b->geo_pending) VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_geo, 0));
     VO_HIP(hipMemcpyAsync(b->h_state.data(), b->ps.st, b->h_state.size() * sizeof(PairState), hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(hipMemcpyAsync(b->h_cnt.data(), b->fs.cnt, b->h_cnt.size() * sizeof(FrameCounters), hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(hipStreamSynchronize(ctx->stream));

@@ -179,6 +179,7 @@ struct vo_ctx {
     vo_params prm;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_geo = nullptr;  // RANSAC / pose / triangulation of a batch run here, under the next run's detection
     DetectTables* d_tables = nullptr;
     void* d_win_cell = nullptr;     // INTER_AREA decimation tables of every window size (vo_detect.hip: CellTab [769][21 + 1])
     void* d_win_pix = nullptr;      // PixTab [769][768]
@@ -210,6 +211,9 @@ struct vo_batch {
     bool frames_dirty = false;
     uint8_t* h_stage = nullptr;      // pinned staging copy of the frames: vo_batch_set_pair returns before the H2D copy ends
     hipEvent_t ev_upload = nullptr;  // recorded after the latest frame upload
+    hipEvent_t ev_match = nullptr;   // matcher of the latest run finished (main stream)
+    hipEvent_t ev_geo = nullptr;     // geometry of the latest run finished (geometry stream)
+    bool geo_pending = false;
     bool upload_pending = false;
 };
 
