@@ -218,7 +218,10 @@ int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes);
  * through the sequential coordinate walk (the path otherwise taken only when the closed-form window
  * coordinates are not exactly representable); results are identical either way.
  * key 1: value != 0 certifies no matcher shortlist, so that EVERY query takes the exact scan of all train rows
- * (otherwise a handful per frame pair); results are identical either way.                                */
+ * (otherwise a handful per frame pair); results are identical either way.
+ * key 2: value != 0 runs the matcher's dense contraction on the FP32 matrix instruction (v_mfma_f32_32x32x2_f32, the
+ * formulation BASELINE's north star names) instead of three split-bf16 products; same shortlist, certificate and
+ * results, about 2.5 times the kernel time.                                                               */
 int vo_debug_set(vo_ctx* ctx, int key, int value);
 
 /* ---- N1: gates and pose chain of the node, host arithmetic only (no GPU, no context) ----------------

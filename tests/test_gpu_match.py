@@ -89,6 +89,27 @@ def test_knn2_unnormalised_descriptors(ctx):
     assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
 
 
+def test_knn2_fp32_mfma_variant_gives_the_same_answer(ctx):
+    """vo_debug_set key 2: the shortlist contraction on v_mfma_f32_32x32x2_f32 (FP32 operands) instead of split bf16."""
+    cases = [(1000, 1200, 61), (333, 31, 62), (4096, 4096, 63), (70, 1, 64)]
+    ctx.debug_set(2, 1)
+    try:
+        for na, nb, seed in cases:
+            a = synth.surf_like_descriptors(na, seed)
+            b = synth.surf_like_descriptors(nb, seed + 100)
+            k = min(na, nb) // 3
+            b[:k] = a[:k] + np.random.default_rng(seed).normal(0, 1e-3, size=(k, 64)).astype(np.float32)
+            idx, dist = ctx.match_knn2(a, b)
+            ridx, rdist = O.match_knn2(a, b)
+            assert np.array_equal(idx, ridx) and np.array_equal(dist.view(np.uint32), rdist.view(np.uint32)), (na, nb)
+        sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 1001)
+        g = ctx.opt_DetectFeatures(sc.img1, sc.img2)
+    finally:
+        ctx.debug_set(2, 0)
+    p1, p2, m = O.detect_match(sc.img1, sc.img2)
+    assert np.array_equal(g.Kpoints1, p1) and np.array_equal(g.match["trainIdx"], m["trainIdx"])
+
+
 def test_knn2_against_numpy(ctx):
     a = synth.surf_like_descriptors(500, 21)
     b = synth.surf_like_descriptors(700, 22)

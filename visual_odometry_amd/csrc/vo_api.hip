@@ -973,6 +973,7 @@ extern "C" int vo_debug_set(vo_ctx* ctx, int key, int value) {
     switch (key) {
         case 0: ctx->force_seq_describe = value ? 1 : 0; return VO_OK;
         case 1: ctx->force_exact_match = value ? 1 : 0; return VO_OK;
+        case 2: ctx->match_fp32 = value ? 1 : 0; return VO_OK;
         default: return VO_ERR_INVALID_ARG;
     }
 }

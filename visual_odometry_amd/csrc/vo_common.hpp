@@ -186,6 +186,7 @@ struct vo_ctx {
     uint32_t* d_rng_raw = nullptr;  // unused placeholder (rng stream is generated on device)
     bool profiling = false;
     int force_seq_describe = 0;     // vo_debug_set key 0
+    int match_fp32 = 0;             // vo_debug_set key 2: shortlist on the FP32 MFMA (v_mfma_f32_32x32x2_f32) instead of split bf16
     int force_exact_match = 0;      // vo_debug_set key 1: no shortlist is certified, every query takes the exact scan
     int* d_redo_cnt = nullptr;      // [1] length of the matcher's redo list; one per context: every launch of a context is
                                     // on its one in-order stream (vo_debug_fetch 4 reads the last launch's value)

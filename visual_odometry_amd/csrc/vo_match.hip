@@ -54,6 +54,8 @@ __device__ __forceinline__ void bf16_split8(const float4& v0, const float4& v1, 
 constexpr int kSlabs = 9;
 // Operand layout of a 32-row tile: 9 slabs of 64 lanes x 16 bytes.  Lane (h, r) of slab m (0..3) holds the high parts of
 // row r, elements 32h + 8m .. + 7; slab 4 + m the low parts; slab 8 the norm term (below).
+// F32: the layout of the FP32-MFMA variant instead (slab s4 = floats 32h + 4 s4 .. + 3 of row r, slab 8 = the norm as one float).
+template <bool F32>
 __global__ __launch_bounds__(64) void k_match_prep(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt,
                                                    int cap, float4* __restrict__ descT_base, float* __restrict__ nrm_base,
                                                    int* __restrict__ nmax_bits) {
@@ -72,17 +74,24 @@ __global__ __launch_bounds__(64) void k_match_prep(const float* __restrict__ des
         if (r < n) v[s4] = row[8 * h + s4];
         ss += v[s4].x * v[s4].x + v[s4].y * v[s4].y + v[s4].z * v[s4].z + v[s4].w * v[s4].w;
     }
+    if (F32) {
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        uint4 hi, lo;
-        bf16_split8(v[2 * m], v[2 * m + 1], hi, lo);
-        reinterpret_cast<uint4*>(out)[m * 64 + lane] = hi;
-        reinterpret_cast<uint4*>(out)[(4 + m) * 64 + lane] = lo;
+        for (int s4 = 0; s4 < 8; s4++) out[s4 * 64 + lane] = v[s4];
+    } else {
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+            uint4 hi, lo;
+            bf16_split8(v[2 * m], v[2 * m + 1], hi, lo);
+            reinterpret_cast<uint4*>(out)[m * 64 + lane] = hi;
+            reinterpret_cast<uint4*>(out)[(4 + m) * 64 + lane] = lo;
+        }
     }
     ss += __shfl_xor(ss, 32, 64);
     const float nb = (r < n) ? -0.5f * ss : -1e30f;
     if (h == 0) nrm_base[(size_t)frame * cap + r] = nb;
-    {   // slab 8: -0.5||b||^2 as three bf16 (24 bits) in k slots 0..2 of lane half 0; the query side holds ones there
+    if (F32) {
+        out[8 * 64 + lane] = make_float4(h == 0 ? nb : 0.f, 0.f, 0.f, 0.f);
+    } else {  // slab 8: -0.5||b||^2 as three bf16 (24 bits) in k slots 0..2 of lane half 0; the query side holds ones there
         uint32_t p0, p1, p2, rest;
         bf16_split(nb, p0, p1);
         bf16_split(nb - __uint_as_float(p0 << 16) - __uint_as_float(p1 << 16), p2, rest);
@@ -172,7 +181,88 @@ __device__ __forceinline__ void bf3_step(f32x16 (&an)[NC], const f32x16 (&ao)[NC
     }
 }
 
-template <int NC>  // 32-query blocks per wavefront
+// The same step on v_mfma_f32_32x32x2_f32 with FP32 operands (the north star's formulation; vo_debug_set key 2): 32 MFMAs of
+// 64 cycles per 32 x 32 tile plus the norm step.  Lane (h, r) supplies element 32h + 4 s4 + e of its row to MFMA (s4, e).
+template <int NC, bool CHECK>
+__device__ __forceinline__ void f32_step(f32x16 (&an)[NC], const f32x16 (&ao)[NC], const uint4* st, const float (&q)[NC][32], int tile_prev,
+                                         float (&bv)[NC][kKeep], int (&bi)[NC][kKeep], float (&t4)[NC]) {
+    const float4* sf = reinterpret_cast<const float4*>(st);
+    float4 t[2];
+    t[0] = sf[0];
+    const float an_norm = sf[8 * 64].x;
+    const f32x16 zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    const f32x16 nterm = __builtin_amdgcn_mfma_f32_32x32x2f32(an_norm, 1.0f, zero, 0, 0, 0);
+#pragma unroll
+    for (int s4 = 0; s4 < 8; s4++) {
+        if (s4 < 7) t[(s4 + 1) & 1] = sf[(s4 + 1) * 64];
+        const float4 a = t[s4 & 1];
+#pragma unroll
+        for (int c = 0; c < NC; c++) an[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[c][4 * s4 + 0], s4 == 0 ? nterm : an[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; c++) an[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[c][4 * s4 + 1], an[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; c++) an[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[c][4 * s4 + 2], an[c], 0, 0, 0);
+#pragma unroll
+        for (int c = 0; c < NC; c++) an[c] = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[c][4 * s4 + 3], an[c], 0, 0, 0);
+        if (CHECK) {  // the 4 NC checks of the previous tile, spread over the eight MFMA groups
+#pragma unroll
+            for (int idx = s4 * 4 * NC / 8; idx < (s4 + 1) * 4 * NC / 8; idx++) bf3_check<NC>(ao, idx % NC, idx / NC, tile_prev, bv, bi, t4);
+        }
+    }
+}
+
+// query operands of one wavefront in the form its MFMA variant takes them
+template <int NC, bool F32>
+struct QueryOps;
+template <int NC>
+struct QueryOps<NC, false> {
+    Bf16Frag qh[NC][4], ql[NC][4];  // elements 32h + 8m .. + 7 of the lane's query row for MFMA m, high and low parts
+    __device__ __forceinline__ void load(const float* __restrict__ desc_base, int fa, int cap, int q0, int l31, int h, int nA) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int row = q0 + 32 * c + l31;
+            const float4* p = reinterpret_cast<const float4*>(desc_base + ((size_t)fa * cap + row) * 64 + 32 * h);
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
+                if (row < nA) {
+                    v0 = p[2 * m];
+                    v1 = p[2 * m + 1];
+                }
+                bf16_split8(v0, v1, qh[c][m].u, ql[c][m].u);
+            }
+        }
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void step(f32x16 (&an)[NC], const f32x16 (&ao)[NC], const uint4* st, int tile_prev, float (&bv)[NC][kKeep],
+                                         int (&bi)[NC][kKeep], float (&t4)[NC]) const {
+        bf3_step<NC, CHECK>(an, ao, st, qh, ql, tile_prev, bv, bi, t4);
+    }
+};
+template <int NC>
+struct QueryOps<NC, true> {
+    float q[NC][32];  // elements 32h .. 32h + 31 of the lane's query row
+    __device__ __forceinline__ void load(const float* __restrict__ desc_base, int fa, int cap, int q0, int l31, int h, int nA) {
+#pragma unroll
+        for (int c = 0; c < NC; c++) {
+            const int row = q0 + 32 * c + l31;
+            const float4* p = reinterpret_cast<const float4*>(desc_base + ((size_t)fa * cap + row) * 64 + 32 * h);
+#pragma unroll
+            for (int s4 = 0; s4 < 8; s4++) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < nA) v = p[s4];
+                q[c][4 * s4 + 0] = v.x, q[c][4 * s4 + 1] = v.y, q[c][4 * s4 + 2] = v.z, q[c][4 * s4 + 3] = v.w;
+            }
+        }
+    }
+    template <bool CHECK>
+    __device__ __forceinline__ void step(f32x16 (&an)[NC], const f32x16 (&ao)[NC], const uint4* st, int tile_prev, float (&bv)[NC][kKeep],
+                                         int (&bi)[NC][kKeep], float (&t4)[NC]) const {
+        f32_step<NC, CHECK>(an, ao, st, q, tile_prev, bv, bi, t4);
+    }
+};
+
+template <int NC, bool F32>  // 32-query blocks per wavefront; F32: FP32 MFMA instead of split bf16
 __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ desc_base, const uint4* __restrict__ descT_base,
                                                    const float* __restrict__ nrm_base, const FrameCounters* __restrict__ cnt, int cap,
                                                    const int2* __restrict__ pair_frames, int ksplit, int bpp, int xcd_map,
@@ -199,22 +289,8 @@ __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ des
     if (qgroup * 4 * 32 * NC >= nA) return;  // no query in the whole workgroup (wavefronts past nA still help with the staging)
     const int ntiles = (nB + 31) >> 5;
 
-    // query operands: the lane's query row, elements 32h + 8m .. + 7 for MFMA m (the same k permutation as the train side)
-    Bf16Frag qh[NC][4], ql[NC][4];
-#pragma unroll
-    for (int c = 0; c < NC; c++) {
-        const int row = q0 + 32 * c + l31;
-        const float4* p = reinterpret_cast<const float4*>(desc_base + ((size_t)fa * cap + row) * 64 + 32 * h);
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            float4 v0 = make_float4(0.f, 0.f, 0.f, 0.f), v1 = v0;
-            if (row < nA) {
-                v0 = p[2 * m];
-                v1 = p[2 * m + 1];
-            }
-            bf16_split8(v0, v1, qh[c][m].u, ql[c][m].u);
-        }
-    }
+    QueryOps<NC, F32> Q;
+    Q.load(desc_base, fa, cap, q0, l31, h, nA);
     float bv[NC][kKeep], t4[NC];
     int bi[NC][kKeep];
 #pragma unroll
@@ -262,22 +338,22 @@ __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ des
         // two accumulator sets: while the MFMAs of step i fill one, the checks of step i - 1 read the other
         f32x16 accA[NC], accB[NC];
         stage_load(tile_of(1));
-        bf3_step<NC, false>(accA, accB, &s_tile[0][lane], qh, ql, 0, bv, bi, t4);
+        Q.template step<false>(accA, accB, &s_tile[0][lane], 0, bv, bi, t4);
         stage_store(1);
         __syncthreads();
         int i = 1;
         for (; i + 1 < nsteps; i += 2) {  // i odd: tile i sits in buffer 1
             stage_load(tile_of(i + 1));
-            bf3_step<NC, true>(accB, accA, &s_tile[1][lane], qh, ql, tile_of(i - 1), bv, bi, t4);
+            Q.template step<true>(accB, accA, &s_tile[1][lane], tile_of(i - 1), bv, bi, t4);
             stage_store(0);
             __syncthreads();
             stage_load(tile_of(i + 2));
-            bf3_step<NC, true>(accA, accB, &s_tile[0][lane], qh, ql, tile_of(i), bv, bi, t4);
+            Q.template step<true>(accA, accB, &s_tile[0][lane], tile_of(i), bv, bi, t4);
             stage_store(1);
             __syncthreads();
         }
         if (i < nsteps) {  // one more tile: into B, then B's checks
-            bf3_step<NC, true>(accB, accA, &s_tile[1][lane], qh, ql, tile_of(i - 1), bv, bi, t4);
+            Q.template step<true>(accB, accA, &s_tile[1][lane], tile_of(i - 1), bv, bi, t4);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -553,8 +629,9 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
         StageScope sc(ctx, ST_MATCH_PREP);
         VO_HIP(hipMemsetAsync(fs.nmax, 0, (size_t)fs.F * sizeof(int), ctx->stream));
         VO_HIP(hipMemsetAsync(ctx->d_redo_cnt, 0, sizeof(int), ctx->stream));
-        hipLaunchKernelGGL(k_match_prep, dim3(cap / 32, fs.F), dim3(64), 0, ctx->stream, fs.desc, fs.cnt, cap,
-                           reinterpret_cast<float4*>(fs.descT), fs.nrm, fs.nmax);
+        auto prep = ctx->match_fp32 ? k_match_prep<true> : k_match_prep<false>;
+        hipLaunchKernelGGL(prep, dim3(cap / 32, fs.F), dim3(64), 0, ctx->stream, fs.desc, fs.cnt, cap, reinterpret_cast<float4*>(fs.descT),
+                           fs.nrm, fs.nmax);
         VO_HIP(hipGetLastError());
     }
     // Train-range splits: one per query block when the batch alone fills the chip (long scans make top-4 insertions rare),
@@ -564,7 +641,8 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
     {
         StageScope sc(ctx, ST_MATCH_MFMA);
         const int bpp = ((cap + 128 * kQueryBlocks - 1) / (128 * kQueryBlocks)) * ksplit;  // workgroups per pair: 4 query blocks of 64, one train split each
-        hipLaunchKernelGGL(k_match_bf3<kQueryBlocks>, dim3(bpp * P), dim3(256), 0, ctx->stream, fs.desc,
+        auto shortlist = ctx->match_fp32 ? k_match_bf3<kQueryBlocks, true> : k_match_bf3<kQueryBlocks, false>;
+        hipLaunchKernelGGL(shortlist, dim3(bpp * P), dim3(256), 0, ctx->stream, fs.desc,
                            reinterpret_cast<const uint4*>(fs.descT), fs.nrm, fs.cnt, cap, ps.frames, ksplit, bpp, (P % 8 == 0) ? 1 : 0,
                            ps.cand_val, ps.cand_idx);
         VO_HIP(hipGetLastError());
