@@ -110,6 +110,35 @@ def test_knn2_fp32_mfma_variant_gives_the_same_answer(ctx):
     assert np.array_equal(g.Kpoints1, p1) and np.array_equal(g.match["trainIdx"], m["trainIdx"])
 
 
+def test_knn2_32k_by_32k_baseline_config_4():
+    """BASELINE configs[3]: 32k descriptors per frame (the distance-matrix stress).  Checked on 768 sampled queries against a
+    numpy restatement of the sequential float32 distance (exact indices, bit-exact distances)."""
+    from visual_odometry_amd._abi import default_params
+    from visual_odometry_amd.frontend import Context
+
+    prm = default_params()
+    prm.kp_capacity = 32768
+    c = Context(prm)
+    try:
+        n = 32768
+        a = synth.surf_like_descriptors(n, 71)
+        b = synth.surf_like_descriptors(n, 72)
+        rng = np.random.default_rng(73)
+        rows = rng.choice(n, 6000, replace=False)
+        b[rows] = a[rng.choice(n, 6000, replace=False)] + rng.normal(0, 3e-3, (6000, 64)).astype(np.float32)
+        idx, dist = c.match_knn2(a, b)
+        for q in rng.choice(n, 768, replace=False):
+            s = np.zeros(n, np.float32)
+            for k in range(64):
+                t = a[q, k] - b[:, k]
+                s += t * t
+            order = np.lexsort((np.arange(n), s))[:2]
+            assert np.array_equal(idx[q], order), (q, idx[q], order)
+            assert np.array_equal(dist[q].view(np.uint32), np.sqrt(s[order]).view(np.uint32)), q
+    finally:
+        c.close()
+
+
 def test_knn2_against_numpy(ctx):
     a = synth.surf_like_descriptors(500, 21)
     b = synth.surf_like_descriptors(700, 22)
