@@ -33,6 +33,22 @@ def main():
         R=R, t=t, good=good, Xk=Xk, tuples_1000=O.ransac_subsets(2**64 - 1, 1000, 16))
     print("c1_small:", len(k), "kp", len(m), "matches", ninl, "inliers", Xk.shape[1], "world points")
 
+    # N2: get_image on a small colour frame (fractional resize 130 x 173 -> 61 x 97, rapallo-like distortion, CLAHE 16 / 8 x 8)
+    from visual_odometry_amd._abi import VoPrepParams
+
+    bgr = synth.bgr_frame(130, 173, 515151)
+    p = VoPrepParams()
+    p.src_rows, p.src_cols, p.dst_rows, p.dst_cols = 130, 173, 61, 97
+    Kp = np.array([[150.0, 0.0, 48.3], [0.0, 149.0, 30.6], [0.0, 0.0, 1.0]])
+    p.K[:] = [float(v) for v in Kp.ravel()]
+    p.dist[:] = [float(v) for v in synth.DIST_RAPALLO]
+    p.clip_limit, p.tiles_x, p.tiles_y = 16.0, 8, 8
+    o = O.prep(p, bgr)
+    np.savez_compressed(os.path.join(HERE, "prep_small.npz"), bgr=bgr, K=Kp, dist=synth.DIST_RAPALLO, dst_shape=np.array([61, 97]),
+                        resized=o["resized"], undist=o["undist"], gray0=o["gray0"], lut=o["lut"], map1=o["map1"], map2=o["map2"],
+                        gray=o["gray"])
+    print("prep_small:", o["gray"].shape, "mean", float(o["gray"].mean()))
+
 
 if __name__ == "__main__":
     main()

@@ -195,3 +195,15 @@ def test_full_chain_at_the_rapallo_size():
     cy, cx = int(round(K[1, 2])), int(round(K[0, 2]))
     assert abs(int(a["map1"][cy, cx, 0]) - cx) <= 1 and abs(int(a["map1"][cy, cx, 1]) - cy) <= 1
     assert 20 <= abs(int(a["map1"][0, 0, 0])) + abs(int(a["map1"][0, 0, 1])) <= 120  # kr = 1.12 at the corner: ~38 px
+
+
+def test_golden_prep_fixture_regression():
+    """tests/golden/prep_small.npz (made by tests/golden/make_golden.py from this oracle): pins later oracle edits and, in
+    tests/test_gpu_golden.py, the device path against a committed input/output set."""
+    import os
+
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "prep_small.npz"))
+    p = make_params(g["bgr"].shape[:2], tuple(int(v) for v in g["dst_shape"]), g["K"], g["dist"])
+    o = O.prep(p, g["bgr"])
+    for k in ("resized", "undist", "gray0", "lut", "map1", "map2", "gray"):
+        assert np.array_equal(o[k], g[k]), k
