@@ -586,7 +586,7 @@ struct LdsTileCfg {
     static constexpr int kBytes = kSumBytes + kLayersPerOctave * T * DP * 4;
 };
 
-template <int T, int O>
+template <int T, int O, int NTH>
 __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b, int frame,
                                                      const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                      int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
@@ -633,28 +633,51 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
         }
     }
     __syncthreads();
-#pragma unroll
-    for (int l = 0; l < kLayersPerOctave; l++) {
-        const LayerTab& L = c_tab.layers[o * kLayersPerOctave + l];
-        // box corners are compile-time constants here: every tap is a ds_read with an immediate offset
-        const int lsize = (9 + 6 * l) << O;
-        const BoxGeom G = box_geom(lsize);
-        const int lmargin = (lsize / 2) / step;
+    // det of sample s of layer l; the box corners are compile-time constants: every tap is a ds_read with an immediate offset
+    auto det_at = [&](auto lc, int s) {
+        constexpr int l = decltype(lc)::value;
+        const LayerTab& L = c_tab.layers[O * kLayersPerOctave + l];
+        constexpr int lsize = (9 + 6 * l) << O;
+        constexpr BoxGeom G = box_geom(lsize);
+        constexpr int lmargin = (lsize / 2) / step;
         const bool fits = (lsize <= H && lsize <= W);
         const int samples_i = fits ? 1 + (H - lsize) / step : 0;
         const int samples_j = fits ? 1 + (W - lsize) / step : 0;
-        const int dm = kMarginMax - lmargin;
-        for (int s = tid; s < T * T; s += NT) {
-            const int yy = s / T, xx = s - yy * T;
-            const int oi = i0 + yy - lmargin, oj = j0 + xx - lmargin;
-            float dv = 0.f;
-            if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
-                float dx, dy, dxy;
-                const LdsTap<O, PP, HALF> tap{(const __attribute__((address_space(3))) int32_t*)s_sum + (yy + dm) * step * PP + (xx + dm)};
-                hessian_boxes_t(G, L.w, tap, dx, dy, dxy);
-                dv = hessian_det(dx, dy, dxy);
+        constexpr int dm = kMarginMax - lmargin;
+        const int yy = s / T, xx = s - yy * T;
+        const int oi = i0 + yy - lmargin, oj = j0 + xx - lmargin;
+        float dv = 0.f;
+        if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
+            float dx, dy, dxy;
+            const LdsTap<O, PP, HALF> tap{(const __attribute__((address_space(3))) int32_t*)s_sum + (yy + dm) * step * PP + (xx + dm)};
+            hessian_boxes_t(G, L.w, tap, dx, dy, dxy);
+            dv = hessian_det(dx, dy, dxy);
+        }
+        s_det[l][yy][xx] = dv;
+    };
+    // whole rounds of NTH samples, layer by layer ...
+    constexpr int kFull = (T * T / NTH) * NTH, kRem = T * T - kFull;
+    if (kFull > 0) {
+        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 0>{}, s);
+        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 1>{}, s);
+        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 2>{}, s);
+        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 3>{}, s);
+        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 4>{}, s);
+    }
+    // ... and the remainder (T * T = 576 = 512 + 64 for the octave-1 tile) with ONE LAYER PER WAVEFRONT, all five at once,
+    // instead of five more rounds in which a single wavefront of the eight has work
+    if (kRem > 0) {
+        static_assert(kRem == 0 || (kRem <= 64 && NTH >= 64 * kLayersPerOctave), "remainder mapping: one wavefront per layer");
+        const int wv = tid >> 6, s = kFull + (tid & 63);
+        if ((tid & 63) < kRem) {
+            switch (wv) {
+                case 0: det_at(std::integral_constant<int, 0>{}, s); break;
+                case 1: det_at(std::integral_constant<int, 1>{}, s); break;
+                case 2: det_at(std::integral_constant<int, 2>{}, s); break;
+                case 3: det_at(std::integral_constant<int, 3>{}, s); break;
+                case 4: det_at(std::integral_constant<int, 4>{}, s); break;
+                default: break;
             }
-            s_det[l][yy][xx] = dv;
         }
     }
     __syncthreads();
@@ -679,7 +702,7 @@ __global__ __launch_bounds__(NTH) void k_hessian_nms_fused(const int32_t* __rest
     if (b < n_rest)
         hessian_nms_global_tile(smem, b, frame, sum_base, sum_stride, g_rest, thr, kp_base, cap, cnt, filter_invalid);
     else
-        hessian_nms_lds_tile<T0, 0>(smem, b - n_rest, frame, sum_base, sum_stride, H, W, tiles_x0, thr, kp_base, cap, cnt,
+        hessian_nms_lds_tile<T0, 0, NTH>(smem, b - n_rest, frame, sum_base, sum_stride, H, W, tiles_x0, thr, kp_base, cap, cnt,
                                     filter_invalid);
 }
 
@@ -688,7 +711,7 @@ __global__ __launch_bounds__(NTH) void k_hessian_nms_lds(const int32_t* __restri
                                                          int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
                                                          FrameCounters* __restrict__ cnt, int filter_invalid) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LdsTileCfg<T, O>::kBytes];
-    hessian_nms_lds_tile<T, O>(smem, blockIdx.x, blockIdx.y, sum_base, sum_stride, H, W, tiles_x, thr, kp_base, cap, cnt,
+    hessian_nms_lds_tile<T, O, NTH>(smem, blockIdx.x, blockIdx.y, sum_base, sum_stride, H, W, tiles_x, thr, kp_base, cap, cnt,
                                filter_invalid);
 }
 
