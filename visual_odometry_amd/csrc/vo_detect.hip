@@ -583,7 +583,11 @@ struct LdsTileCfg {
     static constexpr int PP = O == 0 ? PE : step * HALF;
     static constexpr int DP = T + 1;
     static constexpr int kSumBytes = PE * PP * 4;
-    static constexpr int kBytes = kSumBytes + kLayersPerOctave * T * DP * 4;
+    // the det planes (and the NMS queue behind them) take the patch's place once every tap has been read: LDS per tile is the
+    // larger of the two, not their sum (octave 1: 54 KB instead of 66 KB; octave 0: 25 KB instead of 38 KB)
+    static constexpr int kDetBytes = kLayersPerOctave * T * DP * 4;
+    static constexpr int kOverlayBytes = kDetBytes + (kNmsQueue + 1) * 4;
+    static constexpr int kBytes = kSumBytes > kOverlayBytes ? kSumBytes : kOverlayBytes;
 };
 
 template <int T, int O, int NTH>
@@ -594,7 +598,7 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     using C = LdsTileCfg<T, O>;
     constexpr int TI = C::TI, step = C::step, kMarginMax = C::kMarginMax, PE = C::PE, HALF = C::HALF, PP = C::PP, DP = C::DP;
     int32_t* s_sum = reinterpret_cast<int32_t*>(smem);
-    float (*s_det)[T][DP] = reinterpret_cast<float (*)[T][DP]>(smem + C::kSumBytes);
+    float (*s_det)[T][DP] = reinterpret_cast<float (*)[T][DP]>(smem);  // overlays the patch after the barrier below
     const int o = O;
     const int ty = b / tiles_x, tx = b - ty * tiles_x;
     const int sw = W + 1;
@@ -634,7 +638,7 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     }
     __syncthreads();
     // det of sample s of layer l; the box corners are compile-time constants: every tap is a ds_read with an immediate offset
-    auto det_at = [&](auto lc, int s) {
+    auto det_at = [&](auto lc, int s) -> float {
         constexpr int l = decltype(lc)::value;
         const LayerTab& L = c_tab.layers[O * kLayersPerOctave + l];
         constexpr int lsize = (9 + 6 * l) << O;
@@ -653,37 +657,50 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
             hessian_boxes_t(G, L.w, tap, dx, dy, dxy);
             dv = hessian_det(dx, dy, dxy);
         }
-        s_det[l][yy][xx] = dv;
+        return dv;
     };
-    // whole rounds of NTH samples, layer by layer ...
-    constexpr int kFull = (T * T / NTH) * NTH, kRem = T * T - kFull;
-    if (kFull > 0) {
-        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 0>{}, s);
-        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 1>{}, s);
-        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 2>{}, s);
-        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 3>{}, s);
-        for (int s = tid; s < kFull; s += NTH) det_at(std::integral_constant<int, 4>{}, s);
-    }
+    // whole rounds of NTH samples, layer by layer; the results stay in registers until the patch is dead ...
+    constexpr int kRounds = T * T / NTH, kFull = kRounds * NTH, kRem = T * T - kFull;
+    float dvr[kRounds > 0 ? kRounds : 1][kLayersPerOctave];
+#pragma unroll
+    for (int it = 0; it < kRounds; it++) dvr[it][0] = det_at(std::integral_constant<int, 0>{}, tid + it * NTH);
+#pragma unroll
+    for (int it = 0; it < kRounds; it++) dvr[it][1] = det_at(std::integral_constant<int, 1>{}, tid + it * NTH);
+#pragma unroll
+    for (int it = 0; it < kRounds; it++) dvr[it][2] = det_at(std::integral_constant<int, 2>{}, tid + it * NTH);
+#pragma unroll
+    for (int it = 0; it < kRounds; it++) dvr[it][3] = det_at(std::integral_constant<int, 3>{}, tid + it * NTH);
+#pragma unroll
+    for (int it = 0; it < kRounds; it++) dvr[it][4] = det_at(std::integral_constant<int, 4>{}, tid + it * NTH);
     // ... and the remainder (T * T = 576 = 512 + 64 for the octave-1 tile) with ONE LAYER PER WAVEFRONT, all five at once,
     // instead of five more rounds in which a single wavefront of the eight has work
+    float dv_rem = 0.f;
+    const int wv_rem = tid >> 6, s_rem = kFull + (tid & 63);
+    const bool has_rem = kRem > 0 && (tid & 63) < kRem && wv_rem < kLayersPerOctave;
     if (kRem > 0) {
         static_assert(kRem == 0 || (kRem <= 64 && NTH >= 64 * kLayersPerOctave), "remainder mapping: one wavefront per layer");
-        const int wv = tid >> 6, s = kFull + (tid & 63);
-        if ((tid & 63) < kRem) {
-            switch (wv) {
-                case 0: det_at(std::integral_constant<int, 0>{}, s); break;
-                case 1: det_at(std::integral_constant<int, 1>{}, s); break;
-                case 2: det_at(std::integral_constant<int, 2>{}, s); break;
-                case 3: det_at(std::integral_constant<int, 3>{}, s); break;
-                case 4: det_at(std::integral_constant<int, 4>{}, s); break;
-                default: break;
+        if (has_rem) {
+            switch (wv_rem) {
+                case 0: dv_rem = det_at(std::integral_constant<int, 0>{}, s_rem); break;
+                case 1: dv_rem = det_at(std::integral_constant<int, 1>{}, s_rem); break;
+                case 2: dv_rem = det_at(std::integral_constant<int, 2>{}, s_rem); break;
+                case 3: dv_rem = det_at(std::integral_constant<int, 3>{}, s_rem); break;
+                default: dv_rem = det_at(std::integral_constant<int, 4>{}, s_rem); break;
             }
         }
     }
+    __syncthreads();  // every tap has been read: the patch is dead, the det planes take its place
+#pragma unroll
+    for (int it = 0; it < kRounds; it++) {
+        const int s = tid + it * NTH, yy = s / T, xx = s - yy * T;
+#pragma unroll
+        for (int l = 0; l < kLayersPerOctave; l++) s_det[l][yy][xx] = dvr[it][l];
+    }
+    if (has_rem) s_det[wv_rem][s_rem / T][s_rem % T] = dv_rem;
     __syncthreads();
 
-    // the integral patch is dead from here on: its first words hold the candidate queue
-    nms_tile<TI, DP, T * DP>(&s_det[0][0][0], reinterpret_cast<int*>(s_sum), o, ty, tx, H, W, thr, sum, kp_base + (size_t)frame * cap,
+    // the candidate queue sits behind the det planes
+    nms_tile<TI, DP, T * DP>(&s_det[0][0][0], reinterpret_cast<int*>(smem + C::kDetBytes), o, ty, tx, H, W, thr, sum, kp_base + (size_t)frame * cap,
                              cap, cnt + frame, filter_invalid);
 }
 
