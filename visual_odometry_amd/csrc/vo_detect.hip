@@ -579,7 +579,7 @@ struct LdsTileCfg {
     static constexpr int kSizeMax = (9 + 6 * (kLayersPerOctave - 1)) << O;
     static constexpr int kMarginMax = (kSizeMax / 2) / step;
     static constexpr int PE = (T - 1) * step + kSizeMax + 1;  // patch extent in integral-image pixels
-    static constexpr int HALF = O == 0 ? 0 : (((PE + step - 1) / step - 4 + 7) / 8 * 8 + 4);  // words per column phase, = 4 mod 8
+    static constexpr int HALF = O == 0 ? 0 : (((PE + step - 1) / step + 1) | 1);  // words per column phase: odd, and small enough for three tiles per CU (3 x 53.3 KB)
     static constexpr int PP = O == 0 ? PE : step * HALF;
     static constexpr int DP = T + 1;
     static constexpr int kSumBytes = PE * PP * 4;
