@@ -396,7 +396,7 @@ __device__ bool kp_describable(float cx, float cy, float size, int H, int W) {
 // layer, survivors (a few per cent) are compacted into an LDS queue; the queue is then walked with full wavefronts for
 // the 18 neighbours of the adjacent layers, the interpolation and the append.  Keypoints are appended in
 // arbitrary order (a4 sorts them by a total order).
-constexpr int kNmsQueue = 1023;  // entries; a 2-D strict local maximum is at most every 4th sample of 3 * 32 * 32
+constexpr int kNmsQueue = 768;  // entries: strict 3 x 3 maxima cannot be neighbours, so at most 16 x 16 per layer of a 32 x 32 tile, 3 layers
 
 template <int TI, int DP, int PLANE>
 __device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o, int ty, int tx, int H, int W, float thr,
