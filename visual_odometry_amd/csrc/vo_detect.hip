@@ -1445,7 +1445,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     static_assert(((kPitch / 4) & 1) == 1, "strip pitch must be an odd number of dwords");
     __shared__ CellTab s_cell[kPatch + 1];
     // strip-phase arrays; the gradient planes of the last phase (s_grad, 3200 B) reuse the same bytes
-    constexpr int kOffPix = 0, kOffSx = kOffPix + WHI * (int)sizeof(PixTab), kOffSy = kOffSx + WHI * 4;
+    // the per-pixel decimation table: an LDS copy for the multi-wavefront classes; the one-wavefront classes (small windows)
+    // read the context's global table instead - their occupancy is bounded by LDS per workgroup (measured both ways)
+    constexpr bool kPixLds = NW > 1;
+    constexpr int kOffPix = 0, kOffSx = kOffPix + (kPixLds ? WHI * (int)sizeof(PixTab) : 0), kOffSy = kOffSx + WHI * 4;
     constexpr int kOffWin = (kOffSy + WHI * 4 + 15) & ~15, kOffRowv = (kOffWin + RS * kPitch + 15) & ~15;
     constexpr int kStripBytes = kOffRowv + NBUF * RS * (kPatch + 1) * 4, kGradBytes = 2 * kPatch * kPatch * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStripBytes > kGradBytes ? kStripBytes : kGradBytes];
@@ -1520,9 +1523,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         const int iscale = d_cvRoundD(scale);
         const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
         // the window size's decimation tables (k_build_win_tables)
+        const PixTab* __restrict__ pix_win = kPixLds ? s_pix : g_pix + (size_t)win * kWinTabPitch;
         if (!area_fast) {
             if (tid <= kPatch) s_cell[tid] = g_cell[(size_t)win * (kPatch + 1) + tid];
-            for (int j = tid; j < win; j += NT) s_pix[j] = g_pix[(size_t)win * kWinTabPitch + j];
+            if (kPixLds)
+                for (int j = tid; j < win; j += NT) s_pix[j] = g_pix[(size_t)win * kWinTabPitch + j];
         }
         if (tid == 0) n_code = *(volatile const int*)&list[min(n_item, n_items - 1)];  // look-ahead stage 2: list entry
         const float win_offset = -(float)(win - 1) / 2;
@@ -1675,7 +1680,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const int q = min(q0 + u, nrows - 1);
-                            t[u] = s_pix[i0 + q];
+                            t[u] = pix_win[i0 + q];
                             val[u] = s_rowv[ob + q * (kPatch + 1)];
                         }
 #pragma unroll
