@@ -1881,7 +1881,7 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             // heaviest class first so that its long keypoints overlap the many short ones that follow
             LAUNCH_TILED(ST_DESC_W768, kBigWin, 4, 8, 8, 1, 1, 3, 768);
             LAUNCH_TILED(ST_DESC_W320, kMidWin, 4, 8, 8, 1, 2, 2, 1280);
-            LAUNCH_TILED(ST_DESC_W128, kSmallWin, 1, 8, 8, 4, 4, 1, 5120);
+            LAUNCH_TILED(ST_DESC_W128, kSmallWin, 1, 8, 8, 3, 4, 1, 5120);
             LAUNCH_TILED(ST_DESC_W64, 64, 1, 8, 4, 4, 8, 0, 5120);
 #undef LAUNCH_TILED
             {
