@@ -212,7 +212,9 @@ int vo_seq_set_pair(vo_batch* b, int pair, int frame_a, int frame_b, const doubl
 /* Inspection of the context's last single-call RANSAC (tests): what = 0 tuples [4096][5] int32,
  * 1 nmodels [4096] int32, 2 counts [4096][10] int32, 3 models [4096][10][9] double;
  * what = 4: one int32, the queries of the context's last matcher launch whose MFMA shortlist could not be
- * certified and that took the exact scan instead.                                                 */
+ * certified and that took the exact scan instead; what = 5 / 6: the shortlist that launch stored for
+ * pair 0, [kp_cap][32] int32 block ids (4 * tile + j, -1 = empty) / float block maxima, per query
+ * 8 groups (train split * 2 + lane half) of {3 kept blocks, bound on everything else}.           */
 int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes);
 /* Test hook, no counterpart in the reference.  key 0: value != 0 sends EVERY keypoint's descriptor window
  * through the sequential coordinate walk (the path otherwise taken only when the closed-form window

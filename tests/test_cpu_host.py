@@ -130,3 +130,11 @@ def test_cv_adaptor_and_ros_switch_headers_compile(tmp_path):
                            "-I" + os.path.join(ROOT, "integration", "ros"), os.path.join(ROOT, "tests", "cv_adaptor_check.cpp"), "-o", exe,
                            "-L" + lib_dir, "-lvo_mi355x", "-Wl,-rpath," + lib_dir])
     assert subprocess.call([exe]) == 0  # without arguments: no GPU call, just proves the link
+
+
+def test_matcher_device_code_has_no_mfma_read_hazard():
+    """The matcher reads MFMA accumulators from inline assembly, which the compiler's hazard recogniser does not cover:
+    tools/check_mfma_hazard.py compiles vo_match.hip to gfx950 assembly and checks the wait states itself."""
+    import subprocess
+
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazard.py")]) == 0

@@ -31,6 +31,37 @@ def test_knn2_exact_ties_go_to_lower_index(ctx):
     assert np.all(idx[:50, 0] == np.arange(50)) and np.all(idx[:50, 1] == np.arange(50) + 50)
 
 
+def test_shortlist_scores_of_every_scanned_tile_are_settled(ctx):
+    """The block maxima the MFMA scan stores (vo_debug_fetch 5 / 6) are within split-bf16 accuracy of the true scores for
+    EVERY tile, the last one of a scan included: its accumulators are read right behind the final MFMAs (mfma_settle);
+    a read that is too early loses a partial product (errors of 2e-4 and more, enough to prune a true neighbour)."""
+    import ctypes as C
+
+    a = synth.surf_like_descriptors(200, 9)
+    b = np.concatenate([a[:50], a[:50], synth.surf_like_descriptors(100, 10)])
+    ctx.match_knn2(a, b)
+    cap = 16384
+    ci = np.zeros((cap, 32), np.int32)
+    cv = np.zeros((cap, 32), np.float32)
+    ctx._chk(ctx.lib.vo_debug_fetch(ctx._h, 5, ci.ctypes.data_as(C.c_void_p), C.c_size_t(ci.nbytes)))
+    ctx._chk(ctx.lib.vo_debug_fetch(ctx._h, 6, cv.ctypes.data_as(C.c_void_p), C.c_size_t(cv.nbytes)))
+    S = a.astype(np.float64) @ b.T.astype(np.float64) - 0.5 * (b.astype(np.float64) ** 2).sum(1)
+    worst, seen = 0.0, set()
+    for q in range(a.shape[0]):
+        for g in range(8):  # group = train split * 2 + lane half; slots 0..2 block ids (4 * tile + j), slot 3 the bound
+            for k in range(3):
+                bl = int(ci[q, 4 * g + k])
+                if bl < 0:
+                    continue
+                rows = [(bl >> 2) * 32 + 8 * (bl & 3) + 4 * (g & 1) + e for e in range(4)]
+                rows = [r for r in rows if r < b.shape[0]]
+                if rows:
+                    worst = max(worst, abs(float(cv[q, 4 * g + k]) - S[q, rows].max()))
+                    seen.add(bl >> 2)
+    assert seen == set(range(7))  # every tile of the 200 train rows, first and last steps of each split
+    assert worst < 2e-5, worst  # 3 * 2^-16 * |a||b| = 4.6e-5 is the bound; observed 5e-6
+
+
 def _redo_count(ctx):
     import ctypes as C
 

@@ -961,6 +961,8 @@ extern "C" int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes) {
         case 1: src = ps.nmodels; size = (size_t)ps.max_hyp * sizeof(int); break;
         case 2: src = ps.counts; size = (size_t)ps.max_hyp * kMaxModels * sizeof(int); break;
         case 3: src = ps.models; size = (size_t)ps.max_hyp * kMaxModels * 9 * sizeof(double); break;
+        case 5: src = ps.cand_idx; size = (size_t)ps.kp_cap * 32 * sizeof(int); break;    // matcher shortlist of pair 0: block ids
+        case 6: src = ps.cand_val; size = (size_t)ps.kp_cap * 32 * sizeof(float); break;  // block maxima / bounds
         default: return VO_ERR_INVALID_ARG;
     }
     VO_HIP(hipSetDevice(ctx->device));

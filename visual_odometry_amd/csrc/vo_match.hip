@@ -135,6 +135,16 @@ __device__ __forceinline__ float max4(float a, float b, float c, float d) {  // 
     return m;
 }
 
+// max4 reads accumulator registers from inline assembly, which the compiler's hazard recogniser does not look into: an
+// MFMA result must not be read by a VALU instruction earlier than 19 wait states after a 16-pass MFMA was issued (the
+// hardware does not interlock).  Inside the pipeline every check is separated from the MFMAs that produced its tile by a
+// barrier and two later MFMAs on the in-order matrix pipe; the checks that follow the LAST MFMAs directly wait here first.
+template <int NC>
+__device__ __forceinline__ void mfma_settle(f32x16 (&acc)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; c++) asm volatile("s_nop 15\n\ts_nop 15" : "+v"(acc[c]));
+}
+
 constexpr int kKeep = 3;         // blocks kept per group
 constexpr int kCandStride = 32;  // slots per query in cand_val / cand_idx: 8 groups x (3 block ids | t4)
 
@@ -354,11 +364,13 @@ __global__ __launch_bounds__(256) void k_match_bf3(const float* __restrict__ des
         }
         if (i < nsteps) {  // one more tile: into B, then B's checks
             Q.template step<true>(accB, accA, &s_tile[1][lane], tile_of(i - 1), bv, bi, t4);
+            mfma_settle<NC>(accB);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
                 for (int c = 0; c < NC; c++) bf3_check<NC>(accB, c, j, tile_of(i), bv, bi, t4);
         } else {
+            mfma_settle<NC>(accA);
 #pragma unroll
             for (int j = 0; j < 4; j++)
 #pragma unroll
@@ -636,7 +648,7 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
     }
     // Train-range splits: one per query block when the batch alone fills the chip (long scans make top-4 insertions rare),
     // four for a few pairs so that a single pair still spreads over 512 wavefronts.
-    constexpr int kQueryBlocks = 2;  // 64 queries per wavefront
+    constexpr int kQueryBlocks = 2;
     const int ksplit = (P >= 8) ? 1 : 4;
     {
         StageScope sc(ctx, ST_MATCH_MFMA);
