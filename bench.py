@@ -21,6 +21,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32 MFMA peak (= vector rate); the matcher no longer runs on it
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+N_SIMD, VALU_CLOCK_HZ = 1024, 2.4e9
+SAMPLE_ISSUE_CYCLES = 86  # VALU issue cycles of one bilinear window sample per wavefront
 MFMA_EXEC_FACTOR = 25.0 / 8.0  # executed bf16 MFMA flop per algorithmic FP32 flop of the matcher (split-bf16 products + norm step)
 
 
@@ -206,10 +208,12 @@ def main():
         S_oct = [5 * (H >> o) * (W >> o) for o in range(4)]
         kp1, _ = ctx.detect_describe(scenes[0].img1)
         win = (21 * (kp1["size"].astype(np.float32) * np.float32(1.2) / np.float32(9.0))).astype(np.int64)
-        cls_share = {}
+        cls_share, cls_samples = {}, {}
         for name, lo, hi in (("describe_w64", 0, 64), ("describe_w128", 64, 128), ("describe_w320", 128, 320), ("describe_w768", 320, 768)):
             m = (win > lo) & (win <= hi)
             cls_share[name] = float(m.mean())
+            # bilinear window samples of the class per launch: win^2 per keypoint (frame 1 of the first scene, scaled to kp)
+            cls_samples[name] = frames * kp * float((win[m].astype(np.float64) ** 2).sum()) / max(len(win), 1)
         # ALGORITHMIC bytes / flops per launch (SURVEY 8d per-frame figures x frames per launch; per-kernel shares of them)
         hess_bytes = lambda So: frames * ((I + 8 * So) + (4 * So + 28 * kp * So / S))
         alg = {
@@ -252,6 +256,14 @@ def main():
             out = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
                    "frac": round(achieved / peak, 5), "traffic": traffic.get(name), "launch_ms": round(dur_s * 1e3, 4),
                    "algorithmic_per_launch": work}
+            if name in cls_samples:
+                # What bounds these kernels is VALU issue: a window sample is 24 instructions = 86 issue cycles per wavefront
+                # (10 fp64 / integer coordinate and address operations, 4 byte->float conversions, 4 packed multiplies and the
+                # u8 pack at 4 cycles, 5 FP32 adds at 2; costs measured by tools/ubench/valu_rates.hip).  1024 SIMDs x 2.4 GHz.
+                wsamples = cls_samples[name] / 64.0
+                cyc = dur_s * VALU_CLOCK_HZ * N_SIMD / max(wsamples, 1.0)
+                out["valu_issue"] = {"window_samples_per_launch": round(cls_samples[name]), "cycles_per_wavefront_sample": round(cyc, 1),
+                                     "floor_cycles": SAMPLE_ISSUE_CYCLES, "frac_of_floor": round(SAMPLE_ISSUE_CYCLES / cyc, 4)}
             if bound == "mfma" and args.matcher != "fp32":
                 out["note"] = ("executed bf16 MFMA flop (3.125 x the algorithmic 2*64*N1*N2) against the dense bf16 peak; "
                                f"algorithmic rate {round(work / dur_s / 1e12, 1)} TFLOP/s = "

@@ -901,7 +901,7 @@ struct PixTab {
 
 // orientation (A.5) of one keypoint by one wavefront; writes kpp->angle and *s_dir (lane 0)
 __device__ __forceinline__ void describe_orientation(const int32_t* __restrict__ sum, int sw, int H, int W, float cx, float cy,
-                                                     float s, int lane, int tid, float* s_X, float* s_Y, int* s_A,
+                                                     float s, int lane, int tid, float2* s_XY, int* s_A,
                                                      vo_keypoint* kpp, float* s_dir_p) {
     const int g = 2 * d_cvRoundF(2 * s);
     int nangle = 0;
@@ -943,8 +943,7 @@ __device__ __forceinline__ void describe_orientation(const int32_t* __restrict__
             const unsigned long long m = __ballot(inb);
             if (inb) {
                 const int pos = nangle + __popcll(m & ((1ull << lane) - 1ull));
-                s_X[pos] = X;
-                s_Y[pos] = Y;
+                s_XY[pos] = make_float2(X, Y);
                 s_A[pos] = Ar;
             }
             nangle += __popcll(m);
@@ -953,6 +952,7 @@ __device__ __forceinline__ void describe_orientation(const int32_t* __restrict__
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    nangle = __builtin_amdgcn_readfirstlane(nangle);  // the same in every lane (ballot counts): a scalar trip count
     float best_mod = 0.f, best_x = 0.f, best_y = 0.f;
     int best_i = 1 << 30;
     {
@@ -962,23 +962,33 @@ __device__ __forceinline__ void describe_orientation(const int32_t* __restrict__
         const int i0 = (lane < 36 ? lane : 0) * 5, i1 = i0 + 180;
         typedef float f32x2_t __attribute__((ext_vector_type(2)));
         f32x2_t acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f};
-#pragma unroll 4
-        for (int j = 0; j < nangle; j++) {
+        auto window_step = [&](int j) {
             const int A = s_A[j];
-            const f32x2_t xy = {s_X[j], s_Y[j]};
-            const unsigned d0 = (unsigned)abs(A - i0);
+            const float2 xyv = s_XY[j];  // one 64-bit LDS read straight into the register pair of the packed add
+            const f32x2_t xy = {xyv.x, xyv.y};
+            // |A - i0| - 30 in one instruction (A and i0 are non-negative: the unsigned sum of absolute differences)
+            unsigned dm30;
+            asm("v_sad_u32 %0, %1, %2, %3" : "=v"(dm30) : "v"(A), "v"(i0), "v"(-30));
             // lanes whose window holds the sample add it under EXEC (one packed add per window; skipping a lane is the
             // same as adding +0.f): the kernel is bound by VALU issue, and selects would cost two more instructions each;
             // the empty asm keeps each add a real branch under EXEC instead of two selects + add
-            if (d0 - 30u > 300u) {
+            if (dm30 > 300u) {
                 acc0 += xy;
                 asm volatile("" : "+v"(acc0));
             }
-            if (d0 - 151u < 59u) {
+            if (dm30 - 121u < 59u) {
                 acc1 += xy;
                 asm volatile("" : "+v"(acc1));
             }
+        };
+        int j = 0;
+        for (; j + 4 <= nangle; j += 4) {  // unrolled by hand (the branches under EXEC keep the compiler from doing it)
+            window_step(j);
+            window_step(j + 1);
+            window_step(j + 2);
+            window_step(j + 3);
         }
+        for (; j < nangle; j++) window_step(j);
         const float sx0 = acc0.x, sy0 = acc0.y, sx1 = acc1.x, sy1 = acc1.y;
         const float m0 = sx0 * sx0 + sy0 * sy0;
         if (lane < 36 && m0 > best_mod) {
@@ -1145,7 +1155,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
                                                  const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                  vo_keypoint* __restrict__ kp_base, float* __restrict__ desc_base,
                                                  int cap, const int* __restrict__ list, int* __restrict__ cls_cnt, int cls) {
-    __shared__ float s_X[kOriSamples + 15], s_Y[kOriSamples + 15];
+    __shared__ float2 s_XY[kOriSamples + 15];
     __shared__ int s_A[kOriSamples + 15];
     __shared__ CellTab s_cell[kPatch + 1];
     __shared__ PixTab s_pix[WHI];
@@ -1178,7 +1188,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
 
     // ---------------------------------------------------------------- orientation (A.5), first wavefront
-    if (tid < 64) describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_X, s_Y, s_A, kpp, &s_dir);
+    if (tid < 64) describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_XY, s_A, kpp, &s_dir);
     // ---------------------------------------------------------------- decimation tables (A.6.1)
     const double scale = (double)win / (kPatch + 1);
     const int iscale = d_cvRoundD(scale);
@@ -1281,7 +1291,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
 __global__ __launch_bounds__(256) void k_orientation(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                      vo_keypoint* __restrict__ kp_base, int cap,
                                                      const FrameCounters* __restrict__ cnt) {
-    __shared__ float s_X[4][kOriSamples + 15], s_Y[4][kOriSamples + 15];
+    __shared__ float2 s_XY[4][kOriSamples + 15];
     __shared__ int s_A[4][kOriSamples + 15];
     __shared__ float s_dir[4];
     const int frame = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -1289,7 +1299,7 @@ __global__ __launch_bounds__(256) void k_orientation(const int32_t* __restrict__
     if (k >= min(cnt[frame].n_raw, cap)) return;
     vo_keypoint* kpp = kp_base + (size_t)frame * cap + k;
     const float s = kpp->size * 1.2f / 9.0f;
-    describe_orientation(sum_base + (size_t)frame * sum_stride, W + 1, H, W, kpp->x, kpp->y, s, lane, lane, s_X[wave], s_Y[wave],
+    describe_orientation(sum_base + (size_t)frame * sum_stride, W + 1, H, W, kpp->x, kpp->y, s, lane, lane, s_XY[wave],
                          s_A[wave], kpp, &s_dir[wave]);
 }
 
