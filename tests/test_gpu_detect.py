@@ -55,7 +55,8 @@ def test_keypoints_exact(ctx, shape, nb, seed):
     assert np.all(k["angle"] == -1)
 
 
-@pytest.mark.parametrize("shape,nb,seed", [((480, 640), 700, 1001), ((505, 640), 500, 3003)])
+@pytest.mark.parametrize("shape,nb,seed", [((480, 640), 700, 1001), ((505, 640), 500, 3003),
+                                           ((243, 322), 150, 11)])  # width not a multiple of four: byte-wise footprint kernel
 def test_descriptors_exact(ctx, shape, nb, seed):
     sc = _scene(shape[0], shape[1], nb, seed)
     for img in (sc.img1, sc.img2):

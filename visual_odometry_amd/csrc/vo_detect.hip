@@ -1318,6 +1318,27 @@ __global__ __launch_bounds__(256) void k_quads(const uint8_t* __restrict__ img_b
     quad_base[(size_t)frame * img_stride + (size_t)y * W + x] = p00 | (p01 << 8) | (p10 << 16) | (p11 << 24);
 }
 
+// the same for frames whose rows are 4-byte aligned (W and the frame pitch multiples of four): four pixels per lane from two
+// aligned words + the next byte of each row, one 16-byte store
+__global__ __launch_bounds__(256) void k_quads4(const uint8_t* __restrict__ img_base, size_t img_stride, int H, int W,
+                                                uint32_t* __restrict__ quad_base) {
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, frame = blockIdx.z;
+    if (x >= W) return;
+    const uint8_t* img = img_base + (size_t)frame * img_stride;
+    const uint8_t* r0 = img + (size_t)y * W + x;
+    const uint8_t* r1 = img + (size_t)min(y + 1, H - 1) * W + x;
+    const uint32_t a = *reinterpret_cast<const uint32_t*>(r0), b = *reinterpret_cast<const uint32_t*>(r1);
+    const bool last = x + 4 >= W;  // the frame's last column repeats itself
+    const uint32_t an = last ? a >> 24 : r0[4], bn = last ? b >> 24 : r1[4];
+    const uint64_t a64 = (uint64_t)a | ((uint64_t)an << 32), b64 = (uint64_t)b | ((uint64_t)bn << 32);
+    uint4 q;
+    q.x = (uint32_t)(a64 & 0xffffu) | ((uint32_t)(b64 & 0xffffu) << 16);
+    q.y = (uint32_t)((a64 >> 8) & 0xffffu) | ((uint32_t)((b64 >> 8) & 0xffffu) << 16);
+    q.z = (uint32_t)((a64 >> 16) & 0xffffu) | ((uint32_t)((b64 >> 16) & 0xffffu) << 16);
+    q.w = (uint32_t)((a64 >> 24) & 0xffffu) | ((uint32_t)((b64 >> 24) & 0xffffu) << 16);
+    *reinterpret_cast<uint4*>(quad_base + (size_t)frame * img_stride + (size_t)y * W + x) = q;
+}
+
 // ------------------------------------------------------------------------------------------------
 // a6, main path: descriptor window sampled in compact 2-D blocks.
 //
@@ -1877,8 +1898,12 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
                 hipLaunchKernelGGL(k_classify_scan, dim3(4), dim3(1024), 0, ctx->stream, nkeys, fs.cls_hist, fs.cls_cnt);
                 hipLaunchKernelGGL(k_classify_scatter, gk, dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt, fs.W, nbins, nkeys,
                                    fs.cls_hist, fs.cls_list, ls);
-                hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img,
-                                   fs.img_stride(), fs.H, fs.W, fs.quad);
+                if (fs.W % 4 == 0 && fs.img_stride() % 4 == 0)
+                    hipLaunchKernelGGL(k_quads4, dim3((fs.W / 4 + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img,
+                                       fs.img_stride(), fs.H, fs.W, fs.quad);
+                else
+                    hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img,
+                                       fs.img_stride(), fs.H, fs.W, fs.quad);
             }
 #define LAUNCH_TILED(STAGE, HI, NW, RB, UMAX, G, CH, CLS, GRID)                                                                     \
     {                                                                                                                              \
