@@ -231,6 +231,25 @@ __global__ __launch_bounds__(256) void k_colsum(const uint8_t* __restrict__ img,
     colsum[((size_t)frame * nbands + band) * W + x] = s;
 }
 
+// four columns per lane from aligned words (W and the frame pitch multiples of four)
+__global__ __launch_bounds__(256) void k_colsum4(const uint8_t* __restrict__ img, size_t img_stride, int H, int W,
+                                                 int nbands, int32_t* __restrict__ colsum) {
+    const int frame = blockIdx.z, band = blockIdx.y;
+    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (x >= W) return;
+    const uint8_t* p = img + (size_t)frame * img_stride + (size_t)band * kBand * W + x;
+    const int rows = min(kBand, H - band * kBand);
+    // two columns per accumulator: 16 rows x 255 fit 16 bits
+    uint32_t even = 0, odd = 0;
+    for (int r = 0; r < rows; r++) {
+        const uint32_t v = *reinterpret_cast<const uint32_t*>(p + (size_t)r * W);
+        even += v & 0x00ff00ffu;
+        odd += (v >> 8) & 0x00ff00ffu;
+    }
+    const int4 o = make_int4((int)(even & 0xffffu), (int)(odd & 0xffffu), (int)(even >> 16), (int)(odd >> 16));
+    *reinterpret_cast<int4*>(colsum + ((size_t)frame * nbands + band) * W + x) = o;
+}
+
 // exclusive prefix of the band sums down every column (in place)
 __global__ __launch_bounds__(256) void k_colsum_scan(int W, int nbands, int32_t* __restrict__ colsum) {
     const int frame = blockIdx.y;
@@ -303,7 +322,11 @@ int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs) {
     StageScope sc(ctx, ST_INTEGRAL);
     const int nbands = (fs.H + kBand - 1) / kBand;
     dim3 g1((fs.W + 255) / 256, nbands, fs.F);
-    hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
+    if (fs.W % 4 == 0 && fs.img_stride() % 4 == 0)
+        hipLaunchKernelGGL(k_colsum4, dim3((fs.W / 4 + 255) / 256, nbands, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                           fs.H, fs.W, nbands, fs.colsum);
+    else
+        hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
     hipLaunchKernelGGL(k_colsum_scan, dim3((fs.W + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.W, nbands, fs.colsum);
     dim3 g2(nbands, fs.F);
     const int cpt = (fs.W + 1023) / 1024;
