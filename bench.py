@@ -278,7 +278,7 @@ def main():
         roofline_all = [roof(k) for k in sorted(alg, key=lambda k: -stage_ms.get(k, 0.0))]
 
         cpu = None
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU port is timed at N = 1 only (rank 0 is the only rank there)
             import oracle_lib as O
 
             cores = min(len(os.sched_getaffinity(0)), 16)
