@@ -11,7 +11,7 @@
 //                                        3x3x3 non-max suppression with an LDS candidate queue, sub-sample interpolation,
 //                                        wavefront-ballot compaction; only the keypoint list is written to HBM
 //   k_sort_bitonic (k_rank + k_scatter) : KeypointGreater order, bitonic in LDS (rank sort above 16384 keypoints)
-//   k_orientation                      : dominant orientation, one wavefront per keypoint
+//   k_orientation                      : dominant orientation, two keypoints per wavefront
 //   k_quads, k_classify_*              : 2x2 footprint image; window-class work lists sorted by (frame, tile)
 //   k_describe_tiled<>                 : 64-float descriptor; rotated window sampled in compact 2-D gather blocks from
 //                                        exact closed-form coordinates, INTER_AREA decimation streamed through LDS
@@ -1309,21 +1309,138 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     }  // work queue
 }
 
-// a5 as its own launch: one wavefront per keypoint, four keypoints per workgroup.  Keeping it out of the descriptor
+// Two keypoints per wavefront (one per 32-lane half), for the stand-alone launch.  The 72 windows of a keypoint are the
+// reference's loop i = 0, 5, ... 355; lane L < 24 of a half sums windows 5L, 5L + 120 and 5L + 240, each decided by the
+// reference's own test on |A - i| (one v_sad_u32 and one compare per window), i.e. 9 VALU instructions per sample for two
+// keypoints where the 36-lane form above spends 6 for one.  Samples past a keypoint's count are (+0, +0): adding them
+// changes no bit of a sum.
+__device__ __forceinline__ void orientation_pair(const int32_t* __restrict__ sum, int sw, int H, int W, vo_keypoint* kpp, bool valid,
+                                                 int lane, float2* s_XY, int* s_A) {
+    const int l32 = lane & 31;
+    const float cx = valid ? kpp->x : 0.f, cy = valid ? kpp->y : 0.f;
+    const float s = (valid ? kpp->size : 9.f) * 1.2f / 9.0f;
+    const int g = 2 * d_cvRoundF(2 * s);
+#pragma unroll
+    for (int q = 0; q < 4; q++) {  // 128 slots per half
+        s_XY[q * 32 + l32] = make_float2(0.f, 0.f);
+        s_A[q * 32 + l32] = 0;
+    }
+    wave_sync_lds();
+    int nangle = 0;
+    const bool fits = valid && !(H + 1 < g || W + 1 < g);
+    {
+        const int xm = g / 2;
+        const float wxa = -1.f / ((float)xm * g), wxb = 1.f / ((float)(g - xm) * g);
+        const float wya = 1.f / ((float)g * xm), wyb = -1.f / ((float)g * (g - xm));
+        const float half = (float)(g - 1) / 2;
+        for (int pass = 0; pass < 4; pass++) {
+            const int kk = pass * 32 + l32;
+            bool inb = false;
+            float X = 0, Y = 0;
+            int Ar = 0;
+            if (fits && kk < kOriSamples) {
+                const int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
+                const int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
+                inb = !(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g);
+                if (inb) {
+                    const int32_t* p = sum + (size_t)y * sw + x;
+                    const uint32_t t00 = p[0], t0m = p[xm], t0g = p[g];
+                    const uint32_t tm0 = p[(size_t)xm * sw], tmg = p[(size_t)xm * sw + g];
+                    const uint32_t tg0 = p[(size_t)g * sw], tgm = p[(size_t)g * sw + xm], tgg = p[(size_t)g * sw + g];
+                    const int bxa = (int)(t00 + tgm - tg0 - t0m), bxb = (int)(t0m + tgg - tgm - t0g);
+                    double d = (double)((float)bxa * wxa);
+                    d += (double)((float)bxb * wxb);
+                    const float vx = (float)d;
+                    const int bya = (int)(t00 + tmg - tm0 - t0g), byb = (int)(tm0 + tgg - tg0 - tmg);
+                    d = (double)((float)bya * wya);
+                    d += (double)((float)byb * wyb);
+                    const float vy = (float)d;
+                    const float w = c_tab.aptw[kk];
+                    X = vx * w;
+                    Y = vy * w;
+                    Ar = d_cvRoundF(d_fastAtan2(Y, X));
+                }
+            }
+            const unsigned long long m = __ballot(inb);
+            const unsigned hm = (unsigned)(m >> (lane & 32));  // this half's lanes
+            if (inb) {
+                const int pos = nangle + __popc(hm & ((1u << l32) - 1u));
+                s_XY[pos] = make_float2(X, Y);
+                s_A[pos] = Ar;
+            }
+            nangle += __popc(hm);
+        }
+    }
+    wave_sync_lds();
+    // trip count: the larger of the two halves' counts (a scalar)
+    const int n_u = max(__builtin_amdgcn_readlane(nangle, 0), __builtin_amdgcn_readlane(nangle, 32));
+    const int i0 = (l32 < 24 ? l32 : 0) * 5, i1 = i0 + 120, i2 = i0 + 240;
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    f32x2_t acc0 = {0.f, 0.f}, acc1 = {0.f, 0.f}, acc2 = {0.f, 0.f};
+    auto window_step = [&](int j) {
+        const int A = s_A[j];
+        const float2 xyv = s_XY[j];
+        const f32x2_t xy = {xyv.x, xyv.y};
+        unsigned d0, d1, d2;  // |A - i| - 30: in the window iff < 0 (wraps) or > 300
+        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d0) : "v"(A), "v"(i0), "v"(-30));
+        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d1) : "v"(A), "v"(i1), "v"(-30));
+        asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d2) : "v"(A), "v"(i2), "v"(-30));
+        if (d0 > 300u) {
+            acc0 += xy;
+            asm volatile("" : "+v"(acc0));
+        }
+        if (d1 > 300u) {
+            acc1 += xy;
+            asm volatile("" : "+v"(acc1));
+        }
+        if (d2 > 300u) {
+            acc2 += xy;
+            asm volatile("" : "+v"(acc2));
+        }
+    };
+    int j = 0;
+    for (; j + 4 <= n_u; j += 4) {
+        window_step(j);
+        window_step(j + 1);
+        window_step(j + 2);
+        window_step(j + 3);
+    }
+    for (; j < n_u; j++) window_step(j);
+    float best_mod = 0.f, best_x = 0.f, best_y = 0.f;
+    int best_i = 1 << 30;
+    if (l32 < 24) {  // ascending i: strictly greater only
+        const float m0 = acc0.x * acc0.x + acc0.y * acc0.y;
+        if (m0 > best_mod) best_mod = m0, best_x = acc0.x, best_y = acc0.y, best_i = i0;
+        const float m1 = acc1.x * acc1.x + acc1.y * acc1.y;
+        if (m1 > best_mod) best_mod = m1, best_x = acc1.x, best_y = acc1.y, best_i = i1;
+        const float m2 = acc2.x * acc2.x + acc2.y * acc2.y;
+        if (m2 > best_mod) best_mod = m2, best_x = acc2.x, best_y = acc2.y, best_i = i2;
+    }
+#pragma unroll
+    for (int d = 16; d >= 1; d >>= 1) {  // within the half: larger mod wins, ties go to the smaller i
+        const float om = __shfl_xor(best_mod, d, 64), ox = __shfl_xor(best_x, d, 64), oy = __shfl_xor(best_y, d, 64);
+        const int oi = __shfl_xor(best_i, d, 64);
+        if (om > best_mod || (om == best_mod && oi < best_i)) best_mod = om, best_x = ox, best_y = oy, best_i = oi;
+    }
+    if (!(best_mod > 0.f)) best_x = 0.f, best_y = 0.f;
+    const float dd = d_fastAtan2(-best_y, best_x);
+    if (valid && l32 == 0) kpp->angle = dd;
+}
+
+// a5 as its own launch: two keypoints per wavefront (orientation_pair), eight per workgroup.  Keeping it out of the descriptor
 // kernel takes its registers and LDS off that kernel's budget and leaves no wavefront idle while one computes the angle.
 __global__ __launch_bounds__(256) void k_orientation(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                      vo_keypoint* __restrict__ kp_base, int cap,
                                                      const FrameCounters* __restrict__ cnt) {
-    __shared__ float2 s_XY[4][kOriSamples + 15];
-    __shared__ int s_A[4][kOriSamples + 15];
-    __shared__ float s_dir[4];
-    const int frame = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int k = blockIdx.x * 4 + wave;
-    if (k >= min(cnt[frame].n_raw, cap)) return;
-    vo_keypoint* kpp = kp_base + (size_t)frame * cap + k;
-    const float s = kpp->size * 1.2f / 9.0f;
-    describe_orientation(sum_base + (size_t)frame * sum_stride, W + 1, H, W, kpp->x, kpp->y, s, lane, lane, s_XY[wave],
-                         s_A[wave], kpp, &s_dir[wave]);
+    __shared__ float2 s_XY[8][128];
+    __shared__ int s_A[8][128];
+    const int frame = blockIdx.y, wave = threadIdx.x >> 6, lane = threadIdx.x & 63, hw = wave * 2 + (lane >> 5);
+    const int n = min(cnt[frame].n_raw, cap);
+    if ((blockIdx.x * 4 + wave) * 2 >= n) return;  // neither half has a keypoint
+    const int k = blockIdx.x * 8 + hw;
+    const bool valid = k < n;
+    vo_keypoint* kpp = kp_base + (size_t)frame * cap + (valid ? k : 0);
+    orientation_pair(sum_base + (size_t)frame * sum_stride, W + 1, H, W, kpp, valid, lane, s_XY[hw], s_A[hw]);
 }
 
 // Bilinear footprint image for the descriptor sampler: one aligned 32-bit word per pixel holds the 2x2 taps
@@ -1909,7 +2026,7 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             const size_t ls = (size_t)fs.F * fs.cap;
             {
                 StageScope sc(ctx, ST_ORIENTATION);
-                hipLaunchKernelGGL(k_orientation, dim3((fs.cap + 3) / 4, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
+                hipLaunchKernelGGL(k_orientation, dim3((fs.cap + 7) / 8, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
                                    fs.H, fs.W, fs.kp, fs.cap, fs.cnt);
             }
             {
