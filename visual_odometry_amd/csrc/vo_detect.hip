@@ -121,17 +121,15 @@ __device__ __forceinline__ float d_fastAtan2(float y, float x) {
     const float p3 = -0.3258083974640975f * scale;
     const float p5 = 0.1555786518463281f * scale;
     const float p7 = -0.04432655554792128f * scale;
-    float ax = fabsf(x), ay = fabsf(y);
-    float a, c, c2;
-    if (ax >= ay) {
-        c = ay / (ax + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    } else {
-        c = ax / (ay + (float)DBL_EPSILON);
-        c2 = c * c;
-        a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    }
+    const float ax = fabsf(x), ay = fabsf(y);
+    // the reference's two branches (ax >= ay: ay / (ax + eps); else ax / (ay + eps), a = 90 - ...) with ONE division:
+    // the operands are selected, the arithmetic is the same (a divergent if/else runs the division sequence twice)
+    const bool steep = !(ax >= ay);
+    const float num = steep ? ax : ay, den = (steep ? ay : ax) + (float)DBL_EPSILON;
+    const float c = num / den;
+    const float c2 = c * c;
+    float a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    if (steep) a = 90.f - a;
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
