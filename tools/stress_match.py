@@ -18,7 +18,9 @@ redo_total = 0
 t0 = time.time()
 for i in range(n):
     nb = int(rng.integers(100, 1500))
-    sc = synth.blob_scene(480, 640, synth.K_PARETE, nb, 5000 + i)
+    # every third scene at a random frame size (odd widths take the byte-wise footprint / column-sum kernels)
+    hh, ww = (480, 640) if i % 3 else (int(rng.integers(120, 520)), int(rng.integers(160, 720)))
+    sc = synth.blob_scene(hh, ww, synth.K_PARETE, nb, 5000 + i)
     g = ctx.opt_DetectFeatures(sc.img1, sc.img2)
     r = C.c_int32(0); ctx.lib.vo_debug_fetch(ctx._h, 4, C.byref(r), C.c_size_t(4)); redo_total += r.value
     p1, p2, m = O.detect_match(sc.img1, sc.img2)
