@@ -1616,7 +1616,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     // strip-phase arrays; the gradient planes of the last phase (s_grad, 3200 B) reuse the same bytes
     // the per-pixel decimation table: an LDS copy for the multi-wavefront classes; the one-wavefront classes (small windows)
     // read the context's global table instead - their occupancy is bounded by LDS per workgroup (measured both ways)
-    constexpr bool kPixLds = NW > 1;
+    constexpr bool kPixLds = NW > 1 && WHI <= kMidWin;  // the largest class trades the copy for a fourth workgroup per CU
     constexpr int kOffPix = 0, kOffSx = kOffPix + (kPixLds ? WHI * (int)sizeof(PixTab) : 0), kOffSy = kOffSx + WHI * 4;
     constexpr int kOffWin = (kOffSy + WHI * 4 + 15) & ~15, kOffRowv = (kOffWin + RS * kPitch + 15) & ~15;
     constexpr int kStripBytes = kOffRowv + NBUF * RS * (kPatch + 1) * 4, kGradBytes = 2 * kPatch * kPatch * 4;
@@ -2052,7 +2052,7 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
                            (const CellTab*)ctx->d_win_cell, (const PixTab*)ctx->d_win_pix, fs.dir_sc);                               \
     }
             // heaviest class first so that its long keypoints overlap the many short ones that follow
-            LAUNCH_TILED(ST_DESC_W768, kBigWin, 4, 8, 8, 1, 1, 3, 768);
+            LAUNCH_TILED(ST_DESC_W768, kBigWin, 4, 8, 8, 1, 1, 3, 1024);
             LAUNCH_TILED(ST_DESC_W320, kMidWin, 4, 8, 8, 1, 2, 2, 1280);
             LAUNCH_TILED(ST_DESC_W128, kSmallWin, 1, 8, 8, 3, 4, 1, 5120);
             LAUNCH_TILED(ST_DESC_W64, 64, 1, 8, 4, 4, 8, 0, 5120);
