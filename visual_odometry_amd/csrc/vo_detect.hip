@@ -1614,7 +1614,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     static_assert(((kPitch / 4) & 1) == 1, "strip pitch must be an odd number of dwords");
     __shared__ CellTab s_cell[kPatch + 1];
     // strip-phase arrays; the gradient planes of the last phase (s_grad, 3200 B) reuse the same bytes
-    // the per-pixel decimation table: an LDS copy for the multi-wavefront classes; the one-wavefront classes (small windows)
+    // the per-pixel decimation table: an LDS copy for the 128-320 px class only.  The largest class is bound by LDS per
+    // workgroup (46 KB with the copy = three workgroups per CU, 38 KB without = four: 6.95 -> 6.31 ms); the one-wavefront classes (small windows)
     // read the context's global table instead - their occupancy is bounded by LDS per workgroup (measured both ways)
     constexpr bool kPixLds = NW > 1 && WHI <= kMidWin;  // the largest class trades the copy for a fourth workgroup per CU
     constexpr int kOffPix = 0, kOffSx = kOffPix + (kPixLds ? WHI * (int)sizeof(PixTab) : 0), kOffSy = kOffSx + WHI * 4;
