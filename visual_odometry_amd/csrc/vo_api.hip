@@ -249,6 +249,8 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     vo_frameset_free(ctx->fs);
     vo_pairset_free(ctx->ps);
     if (ctx->d_tmp) hipFree(ctx->d_tmp);
+    if (ctx->h_up) hipHostFree(ctx->h_up);
+    if (ctx->h_down) hipHostFree(ctx->h_down);
     if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
     if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
     if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
@@ -270,9 +272,33 @@ static int check_image(const uint8_t* img, int rows, int cols, size_t step) {
     return VO_OK;
 }
 
+// pinned bounce buffer of the context (up = host -> device, down = device -> host), grown on demand.  The synchronous
+// entry points that use it have nothing in flight when they are entered, so growing it is safe.
+static int ctx_bounce(vo_ctx* ctx, size_t bytes, bool down, uint8_t** out) {
+    uint8_t*& p = down ? ctx->h_down : ctx->h_up;
+    size_t& cap = down ? ctx->h_down_bytes : ctx->h_up_bytes;
+    if (bytes > cap) {
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+        if (p) hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+        const size_t nb = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        VO_HIP(hipHostMalloc((void**)&p, nb, hipHostMallocDefault));
+        cap = nb;
+    }
+    *out = p;
+    return VO_OK;
+}
+
 static int upload_frame(vo_ctx* ctx, FrameSet& fs, int frame, const uint8_t* img, size_t step) {
-    VO_HIP(hipMemcpy2DAsync(fs.img + (size_t)frame * fs.img_stride(), fs.W, img, step, fs.W, fs.H, hipMemcpyHostToDevice,
-                            ctx->stream));
+    uint8_t* up = nullptr;
+    VO_TRY(ctx_bounce(ctx, (size_t)fs.F * fs.img_stride(), false, &up));
+    uint8_t* slot = up + (size_t)frame * fs.img_stride();
+    if (step == (size_t)fs.W)
+        std::memcpy(slot, img, fs.img_stride());
+    else
+        for (int y = 0; y < fs.H; y++) std::memcpy(slot + (size_t)y * fs.W, img + (size_t)y * step, (size_t)fs.W);
+    VO_HIP(hipMemcpyAsync(fs.img + (size_t)frame * fs.img_stride(), slot, fs.img_stride(), hipMemcpyHostToDevice, ctx->stream));
     return VO_OK;
 }
 
@@ -440,8 +466,11 @@ static int stage_points(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n
 }
 
 static int fetch_state(vo_ctx* ctx, PairSet& ps, int pair, PairState& S) {
-    VO_HIP(hipMemcpyAsync(&S, ps.st + pair, sizeof(S), hipMemcpyDeviceToHost, ctx->stream));
+    uint8_t* dn = nullptr;
+    VO_TRY(ctx_bounce(ctx, sizeof(S), true, &dn));
+    VO_HIP(hipMemcpyAsync(dn, ps.st + pair, sizeof(S), hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(hipStreamSynchronize(ctx->stream));
+    std::memcpy(&S, dn, sizeof(S));
     return VO_OK;
 }
 
@@ -488,19 +517,32 @@ extern "C" int vo_detect_match(vo_ctx* ctx, const uint8_t* img1, size_t step1, c
     VO_TRY(upload_frame(ctx, fs, 1, img2, step2));
     VO_TRY(vo_enqueue_detect(ctx, fs, true));
     VO_TRY(vo_enqueue_match(ctx, fs, ps, true));
+    // counters, pair state and the (capacity-sized) result arrays come down through the pinned bounce buffer in one go:
+    // one synchronisation, then plain memcpys of the n_match entries the caller gets
+    const size_t mc = (size_t)ps.match_cap;
+    const size_t o_cnt = 0, o_st = 64, o_p1 = o_st + ((sizeof(PairState) + 63) & ~(size_t)63), o_p2 = o_p1 + mc * 2 * sizeof(float);
+    const size_t o_m = o_p2 + mc * 2 * sizeof(float), total = o_m + mc * sizeof(vo_dmatch);
+    static_assert(2 * sizeof(FrameCounters) <= 64, "bounce layout");
+    uint8_t* dn = nullptr;
+    VO_TRY(ctx_bounce(ctx, total, true, &dn));
+    VO_HIP(hipMemcpyAsync(dn + o_cnt, fs.cnt, 2 * sizeof(FrameCounters), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipMemcpyAsync(dn + o_st, ps.st, sizeof(PairState), hipMemcpyDeviceToHost, ctx->stream));
+    if (p1xy) VO_HIP(hipMemcpyAsync(dn + o_p1, ps.p1, mc * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (p2xy) VO_HIP(hipMemcpyAsync(dn + o_p2, ps.p2, mc * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    if (m) VO_HIP(hipMemcpyAsync(dn + o_m, ps.matches, mc * sizeof(vo_dmatch), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
     PairState S;
     FrameCounters c[2];
-    VO_HIP(hipMemcpyAsync(c, fs.cnt, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-    VO_TRY(fetch_state(ctx, ps, 0, S));
+    std::memcpy(c, dn + o_cnt, sizeof(c));
+    std::memcpy(&S, dn + o_st, sizeof(S));
     if (c[0].n_raw > fs.cap || c[1].n_raw > fs.cap) return VO_ERR_CAPACITY;
     *n = S.n_match;
     if (S.n_match > ps.match_cap || S.n_match > cap) return VO_ERR_CAPACITY;
     const size_t k = (size_t)S.n_match;
     if (k) {
-        if (p1xy) VO_HIP(hipMemcpyAsync(p1xy, ps.p1, k * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (p2xy) VO_HIP(hipMemcpyAsync(p2xy, ps.p2, k * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (m) VO_HIP(hipMemcpyAsync(m, ps.matches, k * sizeof(vo_dmatch), hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP(hipStreamSynchronize(ctx->stream));
+        if (p1xy) std::memcpy(p1xy, dn + o_p1, k * 2 * sizeof(float));
+        if (p2xy) std::memcpy(p2xy, dn + o_p2, k * 2 * sizeof(float));
+        if (m) std::memcpy(m, dn + o_m, k * sizeof(vo_dmatch));
     }
     return VO_OK;
 }

@@ -196,6 +196,12 @@ struct vo_ctx {
     PairSet ps;
     void* d_tmp = nullptr;
     size_t d_tmp_bytes = 0;
+    // pinned bounce buffers of the synchronous entry points: frames go up and results come down through them (a copy
+    // between the device and PAGEABLE memory makes the runtime pin the caller's pages for every call: ~4 ms per frame pair)
+    uint8_t* h_up = nullptr;
+    size_t h_up_bytes = 0;
+    uint8_t* h_down = nullptr;
+    size_t h_down_bytes = 0;
 };
 
 struct vo_batch {
