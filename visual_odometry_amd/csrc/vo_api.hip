@@ -302,6 +302,44 @@ static int upload_frame(vo_ctx* ctx, FrameSet& fs, int frame, const uint8_t* img
     return VO_OK;
 }
 
+// Several device -> host results of a synchronous call through the pinned bounce buffer: add() enqueues the copies,
+// finish() waits once and hands the bytes to the caller's (pageable) buffers.
+struct BounceDown {
+    struct Item {
+        void* dst;
+        size_t off, bytes;
+    };
+    vo_ctx* ctx;
+    uint8_t* base = nullptr;
+    size_t off = 0;
+    Item items[8];
+    int n = 0;
+    int begin(vo_ctx* c, size_t total) {
+        ctx = c;
+        return ctx_bounce(c, total + 8 * 64, true, &base);
+    }
+    int add(void* dst, const void* dev, size_t bytes) {
+        if (!bytes) return VO_OK;
+        VO_HIP(hipMemcpyAsync(base + off, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+        items[n++] = Item{dst, off, bytes};
+        off += (bytes + 63) & ~(size_t)63;
+        return VO_OK;
+    }
+    int finish() {
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n; i++) std::memcpy(items[i].dst, base + items[i].off, items[i].bytes);
+        return VO_OK;
+    }
+};
+
+// host -> device through the pinned buffer, at byte offset `off` of it (the caller sized it with ctx_bounce)
+static int bounce_up(vo_ctx* ctx, uint8_t* up, size_t off, void* dev, const void* src, size_t bytes) {
+    if (!bytes) return VO_OK;
+    std::memcpy(up + off, src, bytes);
+    VO_HIP(hipMemcpyAsync(dev, up + off, bytes, hipMemcpyHostToDevice, ctx->stream));
+    return VO_OK;
+}
+
 static int reset_counters(vo_ctx* ctx, FrameSet& fs) {
     VO_HIP(hipMemsetAsync(fs.cnt, 0, (size_t)fs.F * sizeof(FrameCounters), ctx->stream));
     VO_HIP(hipMemsetAsync(fs.cls_cnt, 0, kClsCntInts * sizeof(int), ctx->stream));
@@ -356,15 +394,20 @@ extern "C" int vo_detect_describe(vo_ctx* ctx, const uint8_t* img, int rows, int
     VO_TRY(upload_frame(ctx, fs, 0, img, step));
     VO_TRY(vo_enqueue_detect(ctx, fs, desc64 != nullptr));
     FrameCounters c;
-    VO_HIP(hipMemcpyAsync(&c, fs.cnt, sizeof(c), hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(hipStreamSynchronize(ctx->stream));
+    {
+        BounceDown dn;
+        VO_TRY(dn.begin(ctx, sizeof(c)));
+        VO_TRY(dn.add(&c, fs.cnt, sizeof(c)));
+        VO_TRY(dn.finish());
+    }
     *n = c.n_raw;
     if (c.n_raw > fs.cap || c.n_raw > cap) return VO_ERR_CAPACITY;
     if (c.n_raw > 0) {
-        VO_HIP(hipMemcpyAsync(kps, fs.kp, (size_t)c.n_raw * sizeof(vo_keypoint), hipMemcpyDeviceToHost, ctx->stream));
-        if (desc64)
-            VO_HIP(hipMemcpyAsync(desc64, fs.desc, (size_t)c.n_raw * 64 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP(hipStreamSynchronize(ctx->stream));
+        BounceDown dn;
+        VO_TRY(dn.begin(ctx, (size_t)c.n_raw * (sizeof(vo_keypoint) + 64 * sizeof(float))));
+        VO_TRY(dn.add(kps, fs.kp, (size_t)c.n_raw * sizeof(vo_keypoint)));
+        if (desc64) VO_TRY(dn.add(desc64, fs.desc, (size_t)c.n_raw * 64 * sizeof(float)));
+        VO_TRY(dn.finish());
     }
     return VO_OK;
 }
@@ -457,11 +500,12 @@ static int stage_points(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n
     VO_TRY(vo_pairset_alloc(ps, 1, 64, std::max(mc, ps.P == 1 && ps.kp_cap == 64 ? ps.match_cap : 0), kMaxHyp));
     float* d1 = as_inliers ? ps.in1 : ps.p1;
     float* d2 = as_inliers ? ps.in2 : ps.p2;
-    if (n > 0) {
-        VO_HIP(hipMemcpyAsync(d1, p1xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-        VO_HIP(hipMemcpyAsync(d2, p2xy, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    }
-    VO_HIP(hipMemcpyAsync(ps.st, &S, sizeof(S), hipMemcpyHostToDevice, ctx->stream));
+    const size_t pb = (size_t)n * 2 * sizeof(float), sb = (sizeof(S) + 63) & ~(size_t)63;
+    uint8_t* up = nullptr;
+    VO_TRY(ctx_bounce(ctx, sb + 2 * pb, false, &up));
+    VO_TRY(bounce_up(ctx, up, 0, ps.st, &S, sizeof(S)));
+    VO_TRY(bounce_up(ctx, up, sb, d1, p1xy, pb));
+    VO_TRY(bounce_up(ctx, up, sb + pb, d2, p2xy, pb));
     return VO_OK;
 }
 
@@ -488,16 +532,18 @@ extern "C" int vo_match_knn2(vo_ctx* ctx, const float* descA, int nA, const floa
     std::memset(c, 0, sizeof(c));
     c[0].n_raw = c[0].n_kp = nA;
     c[1].n_raw = c[1].n_kp = nB;
-    VO_HIP(hipMemcpyAsync(fs.cnt, c, sizeof(c), hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP(hipMemcpyAsync(fs.desc, descA, (size_t)nA * 64 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
-    if (nB > 0)
-        VO_HIP(hipMemcpyAsync(fs.desc + (size_t)cap * 64, descB, (size_t)nB * 64 * sizeof(float), hipMemcpyHostToDevice,
-                              ctx->stream));
+    const size_t bA = (size_t)nA * 64 * sizeof(float), bB = (size_t)nB * 64 * sizeof(float);
+    uint8_t* up = nullptr;
+    VO_TRY(ctx_bounce(ctx, 64 + bA + bB, false, &up));
+    VO_TRY(bounce_up(ctx, up, 0, fs.cnt, c, sizeof(c)));
+    VO_TRY(bounce_up(ctx, up, 64, fs.desc, descA, bA));
+    VO_TRY(bounce_up(ctx, up, 64 + bA, fs.desc + (size_t)cap * 64, descB, bB));
     VO_TRY(vo_enqueue_match(ctx, fs, ctx->ps, false));
-    VO_HIP(hipMemcpyAsync(idx2, ctx->ps.knn_idx, (size_t)nA * 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(hipMemcpyAsync(dist2, ctx->ps.knn_dist, (size_t)nA * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+    BounceDown dn;
+    VO_TRY(dn.begin(ctx, (size_t)nA * 2 * (sizeof(int) + sizeof(float))));
+    VO_TRY(dn.add(idx2, ctx->ps.knn_idx, (size_t)nA * 2 * sizeof(int)));
+    VO_TRY(dn.add(dist2, ctx->ps.knn_dist, (size_t)nA * 2 * sizeof(float)));
+    return dn.finish();
 }
 
 // ---------------------------------------------------------------- opt_DetectFeatures
@@ -679,9 +725,12 @@ extern "C" int vo_relative_pose(vo_ctx* ctx, const float* p1xy, const float* p2x
     if (S.status != VO_OK) return S.status;
     *n_inl = S.n_inl;
     if (S.n_inl > 0) {
-        if (in1xy) VO_HIP(hipMemcpyAsync(in1xy, ctx->ps.in1, (size_t)S.n_inl * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (in2xy) VO_HIP(hipMemcpyAsync(in2xy, ctx->ps.in2, (size_t)S.n_inl * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP(hipStreamSynchronize(ctx->stream));
+        const size_t ib = (size_t)S.n_inl * 2 * sizeof(float);
+        BounceDown dn;
+        VO_TRY(dn.begin(ctx, 2 * ib));
+        if (in1xy) VO_TRY(dn.add(in1xy, ctx->ps.in1, ib));
+        if (in2xy) VO_TRY(dn.add(in2xy, ctx->ps.in2, ib));
+        VO_TRY(dn.finish());
     }
     *success = S.success;
     if (S.success) {
@@ -737,10 +786,11 @@ extern "C" int vo_triang_points(vo_ctx* ctx, const float* in1xy, const float* in
     *m = S.n_world;
     if (S.n_world > cap) return VO_ERR_CAPACITY;
     if (S.n_world > 0 && Xk) {
-        for (int r = 0; r < 3; r++)
-            VO_HIP(hipMemcpyAsync(Xk + (size_t)r * cap, ctx->ps.Xk + (size_t)r * ctx->ps.match_cap, (size_t)S.n_world * sizeof(double),
-                                  hipMemcpyDeviceToHost, ctx->stream));
-        VO_HIP(hipStreamSynchronize(ctx->stream));
+        const size_t wb = (size_t)S.n_world * sizeof(double);
+        BounceDown dn;
+        VO_TRY(dn.begin(ctx, 3 * wb));
+        for (int r = 0; r < 3; r++) VO_TRY(dn.add(Xk + (size_t)r * cap, ctx->ps.Xk + (size_t)r * ctx->ps.match_cap, wb));
+        VO_TRY(dn.finish());
     }
     return VO_OK;
 }
