@@ -197,6 +197,27 @@ def main():
     redo = C.c_int32(-1)  # queries of the last step whose matcher shortlist was not certified (exact scan instead)
     ctx._chk(ctx.lib.vo_debug_fetch(ctx._h, 4, C.byref(redo), C.c_size_t(4)))
 
+    # Latency of the reference's three calls on ONE pair through the synchronous entry points, host buffers in and out - how
+    # the ROS node calls them (reported beside `value`; rank 0 only)
+    single = None
+    if rank == 0:
+        lat = {"opt_DetectFeatures": [], "optRelativePose": [], "triangPoints": []}
+        sc0 = scenes[0]
+        for it in range(13):
+            t0 = time.perf_counter()
+            g = ctx.opt_DetectFeatures(sc0.img1, sc0.img2)
+            t1 = time.perf_counter()
+            _st, R1, tv1, inl1, ok1 = ctx.optRelativePose(g, sc0.K)
+            t2 = time.perf_counter()
+            if ok1:
+                ctx.triangPoints(inl1.Kpoints1, inl1.Kpoints2, R1, tv1, sc0.K)
+            t3 = time.perf_counter()
+            if it >= 3:
+                lat["opt_DetectFeatures"].append(t1 - t0), lat["optRelativePose"].append(t2 - t1), lat["triangPoints"].append(t3 - t2)
+        single = {k + "_ms": round(1e3 * float(np.median(v)), 3) for k, v in lat.items()}
+        single["total_ms"] = round(sum(single.values()), 3)
+        single["note"] = "one 1080p pair, synchronous C-ABI calls with pageable host buffers in and out (median of 10)"
+
     if rank == 0:
         assert rec_all.shape[0] == args.batch * world
         kp = float(rec_all[:, 1:3].mean())
@@ -328,6 +349,7 @@ def main():
                                       "note": "two resident batches on two contexts (two HIP streams) alternating; same work per pair as `value`"},
             "consecutive_frames": {"value": round(seq_rate, 2), "unit": "frame-pairs/s",
                                    "note": "sequence batch: batch + 1 frames detected once each, pair p = (frame p, frame p + 1); not the headline workload"},
+            "single_pair_latency": single,
             "roofline": roofline,
             "roofline_all": roofline_all,
             "cpu_baseline": cpu,
