@@ -8,7 +8,11 @@ from visual_odometry_amd import synth
 from visual_odometry_amd._abi import default_params
 from visual_odometry_amd.frontend import Context
 prm = default_params()
-sc = synth.blob_scene(505, 640, synth.K_PARETE, 700, 77)
+if len(sys.argv) > 1:  # any argument: the 1080p benchmark pair instead of the reference's 640x505
+    prm.roi_x_lo, prm.roi_y_lo, prm.roi_x_hi, prm.roi_y_hi = synth.roi_for(1080, 1920)
+    sc = synth.scene_c2(2002)
+else:
+    sc = synth.blob_scene(505, 640, synth.K_PARETE, 700, 77)
 ctx = Context(prm)
 for _ in range(3): ctx.opt_DetectFeatures(sc.img1, sc.img2)
 ctx.profile_enable(True)

@@ -121,7 +121,13 @@ struct StageTimer {
 };
 
 // ---------------------------------------------------------------- device buffers
-constexpr int kClsCntInts = 64;
+// list lengths [0..4]; then one work-queue ticket counter per (class, list segment), each on a cache line of its own:
+// atomics on one line complete one after the other (~11 ns each), and at the end of a launch every workgroup draws once
+// from every segment
+constexpr int kTicketStride = 32;  // ints = 128 bytes
+constexpr int kTicketBase = 64;
+__host__ __device__ constexpr int ticket_index(int cls, int seg) { return kTicketBase + (cls * 8 + seg) * kTicketStride; }
+constexpr int kClsCntInts = kTicketBase + 5 * 8 * kTicketStride;
 
 struct FrameSet {
     int F = 0, H = 0, W = 0, cap = 0;
@@ -139,7 +145,7 @@ struct FrameSet {
     float2* dir_sc = nullptr;       // [F][cap] (sin, cos) of every keypoint's descriptor direction
     FrameCounters* cnt = nullptr;   // [F]
     int* cls_list = nullptr;        // [5][F*cap] keypoints (frame*cap + k) of each descriptor window class; list 4 = sequential-walk fallback
-    int* cls_cnt = nullptr;         // [kClsCntInts] list lengths [0..4]; work-queue tickets [8 + 8*cls + segment]
+    int* cls_cnt = nullptr;         // [kClsCntInts] list lengths [0..4]; work-queue tickets at ticket_index(cls, segment)
     int* cls_hist = nullptr;        // [4][F*nbins] keypoints per (class, frame, 256-px tile): counting sort of the class lists
     int nbins() const { return ((W + 255) / 256) * ((H + 255) / 256); }
     size_t img_stride() const { return (size_t)H * W; }

@@ -1194,7 +1194,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     // workgroup leaves as soon as its ticket is past the end of the list
     for (;;) {
     __syncthreads();  // previous keypoint's LDS is no longer read
-    if (tid == 0) s_item = atomicAdd(&cls_cnt[8 + 8 * cls], 1);
+    if (tid == 0) s_item = atomicAdd(&cls_cnt[ticket_index(cls, 0)], 1);
     __syncthreads();
     const int item = s_item;
     if (item >= n_items) break;
@@ -1656,7 +1656,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         if (q_next < q_end) return q_next++;
         while (q_tried < 8) {
             const int lo = (int)((long long)n_items * q_seg >> 3), hi = (int)((long long)n_items * (q_seg + 1) >> 3);
-            const int t = lo + atomicAdd(&cls_cnt[8 + 8 * cls + q_seg], chunk);
+            const int t = lo + atomicAdd(&cls_cnt[ticket_index(cls, q_seg)], chunk);
             if (t < hi) {
                 q_next = t + 1;
                 q_end = min(t + chunk, hi);
