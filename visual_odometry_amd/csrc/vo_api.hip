@@ -215,7 +215,13 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
     ctx->prm = p;
     ctx->device = hip_device;
     if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream_geo, hipStreamNonBlocking) != hipSuccess) {
+        hipStreamCreateWithFlags(&ctx->stream_geo, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+        if (ctx->stream_aux) hipStreamDestroy(ctx->stream_aux);
+        if (ctx->stream_geo) hipStreamDestroy(ctx->stream_geo);
         if (ctx->stream) hipStreamDestroy(ctx->stream);
         delete ctx;
         return VO_ERR_HIP;
@@ -231,6 +237,9 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
         if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
         if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
+        hipEventDestroy(ctx->ev_fork);
+        hipEventDestroy(ctx->ev_join);
+        hipStreamDestroy(ctx->stream_aux);
         hipStreamDestroy(ctx->stream_geo);
         hipStreamDestroy(ctx->stream);
         delete ctx;
@@ -245,6 +254,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream_geo);
+    hipStreamSynchronize(ctx->stream_aux);
     resolve_timers(ctx);
     vo_frameset_free(ctx->fs);
     vo_pairset_free(ctx->ps);
@@ -254,6 +264,9 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
     if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
     if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
+    hipEventDestroy(ctx->ev_fork);
+    hipEventDestroy(ctx->ev_join);
+    hipStreamDestroy(ctx->stream_aux);
     hipStreamDestroy(ctx->stream_geo);
     hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -185,6 +185,9 @@ struct vo_ctx {
     vo_params prm;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t stream_aux = nullptr;  // the largest descriptor class runs here, beside the other three (its long keypoints
+                                       // leave a tail in which most CUs idle); joined before the matcher
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t stream_geo = nullptr;  // RANSAC / pose / triangulation of a batch run here, under the next run's detection
     DetectTables* d_tables = nullptr;
     void* d_win_cell = nullptr;     // INTER_AREA decimation tables of every window size (vo_detect.hip: CellTab [769][21 + 1])
