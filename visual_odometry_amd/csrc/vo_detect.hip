@@ -1994,15 +1994,29 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         g2.tile_base[kNumOctaves] = base2;
         constexpr int T0 = 32, T1 = 24;
         const int tx1 = ((fs.W >> 1) + T1 - 3) / (T1 - 2), ty1 = ((fs.H >> 1) + T1 - 3) / (T1 - 2);
+        // the two launches are independent (they append to the same keypoint list through the frame's counter): octave 1 runs
+        // on the auxiliary stream beside the octave-0 grid unless the stage timers are on
+        const bool beside = !ctx->profiling;
+        hipStream_t s_oct1 = beside ? ctx->stream_aux : ctx->stream;
+        if (beside) {
+            VO_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            VO_HIP(hipStreamWaitEvent(ctx->stream_aux, ctx->ev_fork, 0));
+        }
         StageScope* sc1 = new StageScope(ctx, ST_HESSIAN_OCT1);
-        hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1, 512>), dim3(tx1 * ty1, fs.F), dim3(512), 0, ctx->stream, fs.sum, fs.sum_stride(),
+        hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1, 512>), dim3(tx1 * ty1, fs.F), dim3(512), 0, s_oct1, fs.sum, fs.sum_stride(),
                            fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
         delete sc1;
-        StageScope sc0(ctx, ST_HESSIAN_OCT0);
-        const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
-        hipLaunchKernelGGL((k_hessian_nms_fused<T0, 256>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
-                           fs.sum_stride(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
-                           describe ? 1 : 0);
+        {
+            StageScope sc0(ctx, ST_HESSIAN_OCT0);
+            const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
+            hipLaunchKernelGGL((k_hessian_nms_fused<T0, 256>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
+                               fs.sum_stride(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
+                               describe ? 1 : 0);
+        }
+        if (beside) {
+            VO_HIP(hipEventRecord(ctx->ev_join, ctx->stream_aux));
+            VO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_join, 0));
+        }
         VO_HIP(hipGetLastError());
     }
     {
