@@ -2022,7 +2022,8 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
     {
         StageScope sc(ctx, ST_SORT);
         hipLaunchKernelGGL(k_count_clamp, dim3((fs.F + 255) / 256), dim3(256), 0, ctx->stream, fs.cnt, fs.cap, fs.F);
-        if (fs.cap <= kBitonicMax) {
+        // a few frames (a single pair): the rank sort spreads over the chip, the bitonic network is one workgroup per frame
+        if (fs.cap <= kBitonicMax && fs.F >= 16) {
             int np = 1024;
             while (np < fs.cap) np <<= 1;
             const size_t lds = (size_t)np * sizeof(unsigned long long);
