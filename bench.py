@@ -252,7 +252,7 @@ def main():
         # committed rocprofv3 --pmc passes of this same command (profiles/) and apply to the default
         # workload only
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_q_hbm_traffic.json")  # PMC passes of this command
+        tpath = os.path.join(ROOT, "profiles", "r01_r_hbm_traffic.json")  # PMC passes of this command
         if args.batch == 64 and os.path.exists(tpath):
             prefix = {"describe_w64": "k_describe_tiled<64,", "describe_w128": "k_describe_tiled<128,",
                       "describe_w320": "k_describe_tiled<320,", "describe_w768": "k_describe_tiled<768,",
