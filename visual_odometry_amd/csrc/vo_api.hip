@@ -1031,18 +1031,18 @@ extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2
     const size_t mc = ps.match_cap;
     const int nm = std::min(S.n_used, (int)mc);
     if (nm > cap || S.n_world > cap_world) return VO_ERR_CAPACITY;
+    BounceDown dn;  // through the context's pinned buffer: one synchronisation, no pinning of the caller's pages
+    const size_t wb = (size_t)std::max(S.n_world, 0) * sizeof(double);
+    VO_TRY(dn.begin(ctx, (size_t)nm * (4 * sizeof(float) + sizeof(vo_dmatch) + 1) + 3 * wb));
     if (nm > 0) {
-        if (p1xy) VO_HIP(hipMemcpyAsync(p1xy, ps.p1 + pair * mc * 2, (size_t)nm * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (p2xy) VO_HIP(hipMemcpyAsync(p2xy, ps.p2 + pair * mc * 2, (size_t)nm * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
-        if (m) VO_HIP(hipMemcpyAsync(m, ps.matches + pair * mc, (size_t)nm * sizeof(vo_dmatch), hipMemcpyDeviceToHost, ctx->stream));
-        if (mask) VO_HIP(hipMemcpyAsync(mask, ps.mask + pair * mc, (size_t)nm, hipMemcpyDeviceToHost, ctx->stream));
+        if (p1xy) VO_TRY(dn.add(p1xy, ps.p1 + pair * mc * 2, (size_t)nm * 2 * sizeof(float)));
+        if (p2xy) VO_TRY(dn.add(p2xy, ps.p2 + pair * mc * 2, (size_t)nm * 2 * sizeof(float)));
+        if (m) VO_TRY(dn.add(m, ps.matches + pair * mc, (size_t)nm * sizeof(vo_dmatch)));
+        if (mask) VO_TRY(dn.add(mask, ps.mask + pair * mc, (size_t)nm));
     }
     if (Xk && S.n_world > 0)
-        for (int r = 0; r < 3; r++)
-            VO_HIP(hipMemcpyAsync(Xk + (size_t)r * cap_world, ps.Xk + (pair * 3 + r) * mc, (size_t)S.n_world * sizeof(double),
-                                  hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(hipStreamSynchronize(ctx->stream));
-    return VO_OK;
+        for (int r = 0; r < 3; r++) VO_TRY(dn.add(Xk + (size_t)r * cap_world, ps.Xk + (pair * 3 + r) * mc, wb));
+    return dn.finish();
 }
 
 // ---------------------------------------------------------------- inspection of the last single-call RANSAC
