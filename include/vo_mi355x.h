@@ -110,6 +110,12 @@ int vo_integral(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step
 int vo_hessian_layer(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step,
                      int octave, int layer, float* det, float* trace);
 
+/* The same det values as the PRODUCT kernels hold them (the fused Hessian + NMS launches of vo_detect_describe keep the five
+ * planes of an octave in LDS and never write them out; this inspection call makes them store what their NMS reads).
+ * det_all: all 20 layers packed octave-major, layer l of octave o is [rows >> o][cols >> o]; n_floats must be the total.   */
+int vo_hessian_product_det(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step,
+                           float* det_all, size_t n_floats);
+
 /* ---- a1-a6: SURF::create(50,4,3,false,false)->detectAndCompute(img, noArray(), kps, desc)
  * camera_utility.hpp:746-750.  kps/desc64 hold up to cap entries; *n = count written.
  * Keypoints come out in OpenCV's KeypointGreater order.  desc64 may be NULL (detect only:
@@ -189,14 +195,23 @@ typedef struct vo_pair_out {
 
 int vo_batch_create(vo_ctx* ctx, int n_pairs, int rows, int cols, vo_batch** out);
 void vo_batch_destroy(vo_batch* b);
-/* copy one pair's frames host -> device (asynchronous on the batch's copy stream)       */
+/* Copy one pair's frames host -> device.  The frames exist twice on the device: this writes the slot the latest
+ * vo_batch_run does NOT read, through pinned staging memory (the caller's buffers are free when the call returns) and a
+ * copy stream of the batch's own, so the transfer of step k + 1 runs beside the kernels of step k.  Frames that are not
+ * replaced between two runs carry over; every run starts every pair from R = I, t = 0.                                 */
 int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, size_t step1,
                       const uint8_t* img2, size_t step2, const double K[9]);
-/* enqueue the whole pipeline for all pairs; returns without waiting                     */
+/* enqueue the whole pipeline for all pairs on the frames staged so far; returns without waiting.  VO_ERR_INVALID_ARG when
+ * a pair has no camera matrix yet (K[0] or K[4] zero).                                                                  */
 int vo_batch_run(vo_batch* b);
+/* wait for the uploads issued so far and for the latest run                                                            */
 int vo_batch_sync(vo_batch* b);
+/* result record of a pair: waits for the latest run only (the records travel to pinned host memory with the run)       */
 int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out);
-/* optional bulk outputs of a finished pair (any pointer may be NULL)                    */
+/* the same for the latest run (age 0) or the run before it (age 1): a pipelined caller enqueues run k + 1 and then reads
+ * run k's records while k + 1 executes.  The records of a run stay valid until the second run after it is enqueued.    */
+int vo_batch_get_run(vo_batch* b, int age, int pair, vo_pair_out* out);
+/* optional bulk outputs of a pair of the LATEST run (any pointer may be NULL); waits for that run                      */
 int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask,
                         int cap, double* Xk, int cap_world);
 

@@ -40,6 +40,26 @@ def test_hessian_layers_bit_exact(ctx, octave, layer):
     assert np.array_equal(tr.view(np.uint32), rtr.view(np.uint32))
 
 
+@pytest.mark.parametrize("which", ["1080p", "rapallo", "ragged"])
+def test_product_hessian_det_planes_bit_exact(ctx, which):
+    """a2 on the kernels the product runs: the det planes k_hessian_nms_fused (octaves 0, 2, 3) and k_hessian_nms_lds
+    (octave 1) hold in LDS when their NMS reads them, all 20 layers, against the oracle's materialised layers."""
+    if which == "1080p":
+        img = synth.scene_c2(2002).img1
+    elif which == "rapallo":
+        img = _scene(505, 640, 500, 3003).img1
+    else:
+        img = _scene(243, 322, 150, 11).img1
+    planes = ctx.hessian_product_det(img)
+    assert len(planes) == 20
+    for o in range(4):
+        for l in range(5):
+            rdet, _ = O.hessian_layer(img, o, l)
+            got = planes[o * 5 + l]
+            assert got.shape == rdet.shape
+            assert np.array_equal(got.view(np.uint32), rdet.view(np.uint32)), (o, l)
+
+
 def _assert_kps_equal(k, rk):
     assert len(k) == len(rk)
     for f in ("x", "y", "size", "response", "octave", "class_id"):

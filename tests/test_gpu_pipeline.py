@@ -283,3 +283,119 @@ def test_back_to_back_runs_with_new_inputs_in_between(ctx):
     b.run()
     assert fields(b, 0) == ref["A"][0][0] and fields(b, 1) == ref["A"][1][0]  # get without an explicit sync
     b.close()
+
+
+def _rec(o):
+    return (o.status, o.n_kp1, o.n_kp2, o.n_match, o.n_inl, o.n_good, o.n_world, o.success, o.iters, tuple(o.E), tuple(o.R), tuple(o.t))
+
+
+def test_pipelined_runs_with_double_buffered_frames(ctx):
+    """The frame slots: while run k executes, the frames of run k + 1 are staged and uploaded on the copy stream and run
+    k + 1 is enqueued; run k's records are then read with age 1.  Every run must equal a fresh synchronous batch on the
+    same inputs, bit for bit; frames that are not replaced carry over to the other slot."""
+    scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 1001), (500, 3), (900, 4), (650, 8)]]
+    P = 3
+
+    def fresh(pairs):
+        bb = Batch(ctx, P, 480, 640)
+        for i, (a, c) in enumerate(pairs):
+            bb.set_pair(i, a, c, synth.K_PARETE)
+        bb.run()
+        bb.sync()
+        out = [_rec(bb.get(i)) for i in range(P)]
+        bb.close()
+        return out
+
+    steps = []
+    for k in range(5):  # step k: pairs rotate through the scenes, some swapped
+        steps.append([(scenes[(k + i) % 4].img1, scenes[(k + i) % 4].img2) if (k + i) % 2 == 0 else
+                      (scenes[(k + i) % 4].img2, scenes[(k + i) % 4].img1) for i in range(P)])
+    want = [fresh(s) for s in steps]
+    b = Batch(ctx, P, 480, 640)
+    got = [None] * len(steps)
+    for k, s in enumerate(steps):
+        for i, (a, c) in enumerate(s):
+            b.set_pair(i, a, c, synth.K_PARETE)
+        b.run()  # enqueued behind run k - 1, which may still be executing
+        if k > 0:
+            got[k - 1] = [_rec(b.get(i, age=1)) for i in range(P)]
+    got[-1] = [_rec(b.get(i)) for i in range(P)]
+    assert got == want
+    # partial restaging: only pair 1 replaced, pairs 0 and 2 carry over from the other slot
+    b.set_pair(1, scenes[3].img1, scenes[3].img2, synth.K_PARETE)
+    b.run()
+    b.sync()
+    mixed = [steps[-1][0], (scenes[3].img1, scenes[3].img2), steps[-1][2]]
+    assert [_rec(b.get(i)) for i in range(P)] == fresh(mixed)
+    # nothing restaged: same slot again, same records
+    b.run()
+    assert [_rec(b.get(i)) for i in range(P)] == fresh(mixed)
+    b.close()
+
+
+def test_batch_without_camera_matrix_is_rejected(ctx):
+    from visual_odometry_amd.frontend import VoError
+
+    b = Batch(ctx, 2, 480, 640)
+    sc = synth.blob_scene(480, 640, synth.K_PARETE, 300, 5)
+    b.set_pair(0, sc.img1, sc.img2, sc.K)  # pair 1 never gets a K
+    with pytest.raises(VoError) as e:
+        b.run()
+    assert e.value.status == -1
+    b.close()
+
+
+def test_failed_pair_reports_identity_pose_not_the_previous_runs(ctx):
+    """Every run starts every pair from R = I, t = 0: a pair that fails after a successful run must not report that run's pose."""
+    sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 1001)
+    flat = np.full((480, 640), 128, np.uint8)
+    b = Batch(ctx, 1, 480, 640)
+    b.set_pair(0, sc.img1, sc.img2, sc.K)
+    b.run()
+    o = b.get(0)
+    assert o.success == 1 and not np.allclose(np.array(o.R), np.eye(3).ravel())
+    b.set_pair(0, flat, flat, sc.K)
+    b.run()
+    o = b.get(0)
+    assert o.success == 0 and o.n_match == 0
+    assert np.array_equal(np.array(o.R), np.eye(3).ravel()) and np.array_equal(np.array(o.t), np.zeros(3))
+    b.close()
+
+
+def test_two_seeds_on_one_device_do_not_share_a_sample_stream():
+    """The cv::RNG tables belong to the context and are keyed by seed: a batch whose geometry is still in flight keeps its
+    stream when a single call (same context) or a second context asks for another seed."""
+    from visual_odometry_amd._abi import default_params
+    from visual_odometry_amd.frontend import Context
+
+    sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 1001)
+    p1, p2, _, _, _ = synth.correspondences(1500, synth.K_PARETE, 9, inlier_frac=0.5, noise_px=0.5, h=480, w=640)
+    prm_a, prm_b = default_params(), default_params()
+    prm_b.ransac_seed = 777
+    ca, cb = Context(prm_a), Context(prm_b)
+    ref_a = ca.essential_ransac(p1, p2, synth.K_PARETE, seed=2**64 - 1)
+    ref_b = ca.essential_ransac(p1, p2, synth.K_PARETE, seed=777)
+    assert ref_a[4] != ref_b[4] or not np.array_equal(ref_a[2], ref_b[2])  # the two seeds do give different runs
+    ba, bb = Batch(ca, 4, 480, 640), Batch(cb, 4, 480, 640)
+    for i in range(4):
+        ba.set_pair(i, sc.img1, sc.img2, sc.K)
+        bb.set_pair(i, sc.img1, sc.img2, sc.K)
+    ba.run()
+    ba.sync()
+    bb.run()
+    bb.sync()
+    want_a, want_b = [_rec(ba.get(i)) for i in range(4)], [_rec(bb.get(i)) for i in range(4)]
+    assert want_a != want_b
+    for rep in range(3):
+        ba.run()
+        bb.run()  # second context, other seed, same device, no sync in between
+        got_single = ca.essential_ransac(p1, p2, synth.K_PARETE, seed=777)  # other seed on ca while its batch is in flight
+        assert got_single[4] == ref_b[4] and np.array_equal(got_single[2], ref_b[2]) and np.array_equal(got_single[1], ref_b[1])
+        assert [_rec(ba.get(i)) for i in range(4)] == want_a
+        assert [_rec(bb.get(i)) for i in range(4)] == want_b
+    # more seeds than a context keeps tables for: the oldest is recycled after a drain
+    for s in range(1, 12):
+        ca.essential_ransac(p1, p2, synth.K_PARETE, seed=s)
+    again = ca.essential_ransac(p1, p2, synth.K_PARETE, seed=2**64 - 1)
+    assert again[4] == ref_a[4] and np.array_equal(again[2], ref_a[2])
+    ba.close(), bb.close(), ca.close(), cb.close()

@@ -15,6 +15,8 @@ void vo_set_hip_error(const char* what, hipError_t e, const char* file, int line
     g_hip_err = buf;
 }
 
+void vo_set_error_text(const char* text) { g_hip_err = text; }
+
 extern "C" int vo_abi_version(void) { return VO_ABI_VERSION; }
 
 extern "C" const char* vo_last_hip_error(void) { return g_hip_err.c_str(); }
@@ -59,17 +61,17 @@ extern "C" void vo_params_default(vo_params* p) {
 }
 
 // ---------------------------------------------------------------- profiling
-StageScope::StageScope(vo_ctx* c, int s) : ctx(c), stage(s) {
+StageScope::StageScope(vo_ctx* c, int s, hipStream_t on) : ctx(c), stage(s), stream(on ? on : c->stream) {
     if (!ctx->profiling) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) {
         a = b = nullptr;
         return;
     }
-    hipEventRecord(a, ctx->stream);
+    hipEventRecord(a, stream);
 }
 StageScope::~StageScope() {
     if (!a) return;
-    hipEventRecord(b, ctx->stream);
+    hipEventRecord(b, stream);
     ctx->timers[stage].pending.emplace_back(a, b);
 }
 
@@ -233,7 +235,9 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         st = VO_ERR_HIP;
     if (st == VO_OK) st = vo_build_window_tables(ctx);
     if (st == VO_OK) st = vo_geometry_init(ctx);
+    if (st == VO_OK) st = vo_detect_init(ctx);
     if (st != VO_OK) {
+        vo_geometry_release(ctx);
         if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
         if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
         if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
@@ -258,6 +262,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     resolve_timers(ctx);
     vo_frameset_free(ctx->fs);
     vo_pairset_free(ctx->ps);
+    vo_geometry_release(ctx);
     if (ctx->d_tmp) hipFree(ctx->d_tmp);
     if (ctx->h_up) hipHostFree(ctx->h_up);
     if (ctx->h_down) hipHostFree(ctx->h_down);
@@ -394,6 +399,30 @@ extern "C" int vo_hessian_layer(vo_ctx* ctx, const uint8_t* img, int rows, int c
     return VO_OK;
 }
 
+// det planes of all 20 layers as the PRODUCT kernels (k_hessian_nms_fused / k_hessian_nms_lds) hold them in LDS when their
+// NMS runs - not the inspection kernel of vo_hessian_layer.  Packed layer after layer (octave-major), [rows >> o][cols >> o].
+extern "C" int vo_hessian_product_det(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step, float* det_all,
+                                      size_t n_floats) {
+    if (!ctx || !det_all) return VO_ERR_INVALID_ARG;
+    VO_TRY(check_image(img, rows, cols, step));
+    size_t S = 0;
+    for (int o = 0; o < kNumOctaves; o++) S += (size_t)kLayersPerOctave * (rows >> o) * (cols >> o);
+    if (n_floats != S) return VO_ERR_INVALID_ARG;
+    VO_HIP(hipSetDevice(ctx->device));
+    FrameSet& fs = ctx->fs;
+    VO_TRY(vo_frameset_alloc(fs, 1, rows, cols, ctx->prm.kp_capacity));
+    VO_TRY(reset_counters(ctx, fs));
+    VO_TRY(upload_frame(ctx, fs, 0, img, step));
+    VO_TRY(vo_enqueue_integral(ctx, fs));
+    void* tmp = nullptr;
+    VO_TRY(vo_ctx_tmp(ctx, S * sizeof(float), &tmp));
+    VO_HIP(hipMemsetAsync(tmp, 0xff, S * sizeof(float), ctx->stream));  // NaN pattern: a sample no tile wrote would show
+    VO_TRY(vo_enqueue_hessian_nms(ctx, fs, true, (float*)tmp));
+    VO_HIP(hipMemcpyAsync(det_all, tmp, S * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    return VO_OK;
+}
+
 // ---------------------------------------------------------------- a1-a6
 extern "C" int vo_detect_describe(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step, vo_keypoint* kps,
                                   float* desc64, int cap, int* n) {
@@ -498,6 +527,19 @@ void vo_pairset_free(PairSet& ps) {
 
 static int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
+// The context's own pair buffers (P = 1) of the single-call entry points only ever GROW: the node calls opt_DetectFeatures,
+// optRelativePose and triangPoints once per frame, with different sizes, and re-allocating ~24 device buffers between them
+// (hipFree synchronises the device) cost more than the kernels.  With one pair the strides do not matter to any kernel.
+static int ctx_pairset(vo_ctx* ctx, int kp_cap, int match_cap) {
+    PairSet& ps = ctx->ps;
+    if (ps.st && ps.P == 1) {
+        if (ps.kp_cap >= kp_cap && ps.match_cap >= match_cap) return VO_OK;
+        kp_cap = std::max(kp_cap, ps.kp_cap);
+        match_cap = std::max(match_cap, ps.match_cap);
+    }
+    return vo_pairset_alloc(ps, 1, kp_cap, match_cap, kMaxHyp);
+}
+
 static void init_state(PairState& S, int n, const double* K) {
     std::memset(&S, 0, sizeof(S));
     S.n_match = S.n_used = n;
@@ -509,8 +551,7 @@ static void init_state(PairState& S, int n, const double* K) {
 // single pair of point lists on the device (P = 1)
 static int stage_points(vo_ctx* ctx, const float* p1xy, const float* p2xy, int n, PairState& S, bool as_inliers) {
     PairSet& ps = ctx->ps;
-    const int mc = round_up(std::max(n, 64), 64);
-    VO_TRY(vo_pairset_alloc(ps, 1, 64, std::max(mc, ps.P == 1 && ps.kp_cap == 64 ? ps.match_cap : 0), kMaxHyp));
+    VO_TRY(ctx_pairset(ctx, 64, round_up(std::max(n, 64), 64)));
     float* d1 = as_inliers ? ps.in1 : ps.p1;
     float* d2 = as_inliers ? ps.in2 : ps.p2;
     const size_t pb = (size_t)n * 2 * sizeof(float), sb = (sizeof(S) + 63) & ~(size_t)63;
@@ -540,7 +581,7 @@ extern "C" int vo_match_knn2(vo_ctx* ctx, const float* descA, int nA, const floa
     const int cap = round_up(std::max(std::max(nA, nB), 64), 64);
     FrameSet& fs = ctx->fs;
     VO_TRY(vo_frameset_alloc(fs, 2, 16, 16, cap));
-    VO_TRY(vo_pairset_alloc(ctx->ps, 1, cap, 64, kMaxHyp));
+    VO_TRY(ctx_pairset(ctx, cap, 64));
     FrameCounters c[2];
     std::memset(c, 0, sizeof(c));
     c[0].n_raw = c[0].n_kp = nA;
@@ -570,7 +611,7 @@ extern "C" int vo_detect_match(vo_ctx* ctx, const uint8_t* img1, size_t step1, c
     FrameSet& fs = ctx->fs;
     PairSet& ps = ctx->ps;
     VO_TRY(vo_frameset_alloc(fs, 2, rows, cols, ctx->prm.kp_capacity));
-    VO_TRY(vo_pairset_alloc(ps, 1, ctx->prm.kp_capacity, round_up(ctx->prm.match_capacity, 64), kMaxHyp));
+    VO_TRY(ctx_pairset(ctx, ctx->prm.kp_capacity, round_up(ctx->prm.match_capacity, 64)));
     VO_TRY(reset_counters(ctx, fs));
     VO_TRY(upload_frame(ctx, fs, 0, img1, step1));
     VO_TRY(upload_frame(ctx, fs, 1, img2, step2));
@@ -625,7 +666,7 @@ extern "C" int vo_essential_ransac(vo_ctx* ctx, const float* p1xy, const float* 
     o.thr_px = thr_px;
     o.max_iters = max_iters;
     o.seed = seed;
-    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o, ctx->stream));
     VO_HIP(hipMemcpyAsync(mask, ctx->ps.mask, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
     VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
     if (iters_run) *iters_run = S.iters_run;
@@ -705,7 +746,7 @@ extern "C" int vo_recover_pose(vo_ctx* ctx, const double E[9], const float* p1xy
     o.run_ransac = o.run_triang = false;
     o.gate = false;
     o.dist_thresh = dist_thresh;
-    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o, ctx->stream));
     VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
     std::memcpy(R, S.R, 9 * sizeof(double));
     std::memcpy(t, S.t, 3 * sizeof(double));
@@ -733,7 +774,7 @@ extern "C" int vo_relative_pose(vo_ctx* ctx, const float* p1xy, const float* p2x
     o.max_iters = ctx->prm.ransac_max_iters;
     o.seed = ctx->prm.ransac_seed;
     o.dist_thresh = ctx->prm.distance_threshold;
-    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o, ctx->stream));
     VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
     if (S.status != VO_OK) return S.status;
     *n_inl = S.n_inl;
@@ -794,7 +835,7 @@ extern "C" int vo_triang_points(vo_ctx* ctx, const float* in1xy, const float* in
     VO_TRY(stage_points(ctx, in1xy, in2xy, n, S, true));
     GeoOptions o;
     o.run_ransac = o.run_pose = false;
-    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o));
+    VO_TRY(vo_enqueue_geometry(ctx, ctx->ps, o, ctx->stream));
     VO_TRY(fetch_state(ctx, ctx->ps, 0, S));
     *m = S.n_world;
     if (S.n_world > cap) return VO_ERR_CAPACITY;
@@ -827,20 +868,33 @@ static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq
         vo_batch_destroy(b);
         return st;
     }
-    if (hipHostMalloc((void**)&b->h_stage, (size_t)n_frames * rows * cols, hipHostMallocDefault) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_upload, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_match, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&b->ev_geo, hipEventDisableTiming) != hipSuccess) {
-        vo_set_hip_error("hipHostMalloc/hipEventCreate", hipGetLastError(), __FILE__, __LINE__);
+    const size_t fbytes = (size_t)n_frames * rows * cols;
+    b->d_img[0] = b->fs.img;  // owned by the frame set
+    bool ok = hipMalloc((void**)&b->d_img[1], fbytes + 256) == hipSuccess &&
+              hipStreamCreateWithFlags(&b->stream_copy, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&b->ev_match, hipEventDisableTiming) == hipSuccess;
+    for (int s = 0; s < 2 && ok; s++) {
+        RunHost& rh = b->rh[s];
+        ok = hipHostMalloc((void**)&b->h_stage[s], fbytes, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&rh.init, (size_t)n_pairs * sizeof(PairState), hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&rh.res, (size_t)n_pairs * sizeof(PairState), hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&rh.frames, (size_t)n_pairs * sizeof(int2), hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc((void**)&rh.cnt, (size_t)n_frames * sizeof(FrameCounters), hipHostMallocDefault) == hipSuccess &&
+             hipEventCreateWithFlags(&b->ev_h2d[s], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b->ev_img_free[s], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&rh.ev_state, hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&rh.ev_done, hipEventDisableTiming) == hipSuccess;
+    }
+    if (!ok) {
+        vo_set_hip_error("batch allocation (hipMalloc / hipHostMalloc / hipEventCreate)", hipGetLastError(), __FILE__, __LINE__);
         vo_batch_destroy(b);
         return VO_ERR_HIP;
     }
-    b->h_state.resize(n_pairs);
-    b->h_cnt.resize(n_frames);
+    b->h_init.resize(n_pairs);
     b->h_frames.resize(n_pairs);
+    b->staged.assign(n_frames, 0);
     for (int p = 0; p < n_pairs; p++) b->h_frames[p] = is_seq ? make_int2(p, p + 1) : make_int2(2 * p, 2 * p + 1);
-    b->frames_dirty = is_seq;  // vo_pairset_alloc wrote the (2p, 2p+1) default
-    for (auto& S : b->h_state) init_state(S, 0, nullptr);
+    for (auto& S : b->h_init) init_state(S, 0, nullptr);
     *out = b;
     return VO_OK;
 }
@@ -856,21 +910,46 @@ extern "C" int vo_seq_create(vo_ctx* ctx, int n_frames, int rows, int cols, vo_b
     return batch_create_impl(ctx, n_frames, n_frames - 1, true, rows, cols, out);
 }
 
+// First frame staged into the fill slot since the latest run: its staging memory must have left the host (the upload issued
+// two runs ago) and, on the device, the run that read the slot must be past description before the copy stream overwrites it.
+static int begin_fill(vo_batch* b) {
+    if (b->n_staged) return VO_OK;
+    const int s = b->fill_slot;
+    if (b->h2d_pending[s]) {
+        VO_HIP(hipEventSynchronize(b->ev_h2d[s]));
+        b->h2d_pending[s] = false;
+    }
+    if (b->img_free_pending[s]) {
+        VO_HIP(hipStreamWaitEvent(b->stream_copy, b->ev_img_free[s], 0));
+        b->img_free_pending[s] = false;
+    }
+    return VO_OK;
+}
+
+int vo_batch_frame_slot(vo_batch* b, int frame, uint8_t** d_dst) {
+    if (!b || !d_dst || frame < 0 || frame >= b->n_frames) return VO_ERR_INVALID_ARG;
+    VO_TRY(begin_fill(b));
+    if (!b->staged[frame]) {
+        b->staged[frame] = 1;
+        b->n_staged++;
+    }
+    *d_dst = b->d_img[b->fill_slot] + (size_t)frame * b->fs.img_stride();
+    return VO_OK;
+}
+
 static int stage_frame(vo_batch* b, int frame, const uint8_t* img, size_t step) {
     // the caller's buffer may be pageable and may be reused as soon as this returns: the frame goes through the batch's
-    // pinned staging copy, the H2D transfer itself is asynchronous on the context's stream
-    if (b->upload_pending) {
-        VO_HIP(hipEventSynchronize(b->ev_upload));  // staging slots of the previous step are free again
-        b->upload_pending = false;
-    }
+    // pinned staging copy; the H2D transfer itself is asynchronous on the batch's COPY stream, into the frame slot the
+    // latest run does not read, so it runs beside that run's kernels
+    uint8_t* d_dst = nullptr;
+    VO_TRY(vo_batch_frame_slot(b, frame, &d_dst));
     const size_t fbytes = (size_t)b->rows * b->cols;
-    uint8_t* dst = b->h_stage + (size_t)frame * fbytes;
+    uint8_t* dst = b->h_stage[b->fill_slot] + (size_t)frame * fbytes;
     if (step == (size_t)b->cols)
         std::memcpy(dst, img, fbytes);
     else
         for (int r = 0; r < b->rows; r++) std::memcpy(dst + (size_t)r * b->cols, img + (size_t)r * step, b->cols);
-    VO_HIP(hipMemcpyAsync(b->fs.img + (size_t)frame * b->fs.img_stride(), dst, fbytes, hipMemcpyHostToDevice, b->ctx->stream));
-    b->state_dirty = true;
+    VO_HIP(hipMemcpyAsync(d_dst, dst, fbytes, hipMemcpyHostToDevice, b->stream_copy));
     return VO_OK;
 }
 
@@ -885,9 +964,7 @@ extern "C" int vo_seq_set_pair(vo_batch* b, int pair, int frame_a, int frame_b, 
     if (!b || !b->is_seq || pair < 0 || pair >= b->n_pairs || !K) return VO_ERR_INVALID_ARG;
     if (frame_a < 0 || frame_a >= b->n_frames || frame_b < 0 || frame_b >= b->n_frames) return VO_ERR_INVALID_ARG;
     b->h_frames[pair] = make_int2(frame_a, frame_b);
-    b->frames_dirty = true;
-    init_state(b->h_state[pair], 0, K);
-    b->state_dirty = true;
+    init_state(b->h_init[pair], 0, K);
     return VO_OK;
 }
 
@@ -896,12 +973,25 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
     hipSetDevice(b->ctx->device);
     hipStreamSynchronize(b->ctx->stream);
     hipStreamSynchronize(b->ctx->stream_geo);
+    if (b->stream_copy) hipStreamSynchronize(b->stream_copy);
+    if (b->d_img[0]) b->fs.img = b->d_img[0];
     vo_frameset_free(b->fs);
     vo_pairset_free(b->ps);
-    if (b->h_stage) hipHostFree(b->h_stage);
-    if (b->ev_upload) hipEventDestroy(b->ev_upload);
+    if (b->d_img[1]) hipFree(b->d_img[1]);
+    for (int s = 0; s < 2; s++) {
+        RunHost& rh = b->rh[s];
+        if (b->h_stage[s]) hipHostFree(b->h_stage[s]);
+        if (rh.init) hipHostFree(rh.init);
+        if (rh.res) hipHostFree(rh.res);
+        if (rh.frames) hipHostFree(rh.frames);
+        if (rh.cnt) hipHostFree(rh.cnt);
+        if (b->ev_h2d[s]) hipEventDestroy(b->ev_h2d[s]);
+        if (b->ev_img_free[s]) hipEventDestroy(b->ev_img_free[s]);
+        if (rh.ev_state) hipEventDestroy(rh.ev_state);
+        if (rh.ev_done) hipEventDestroy(rh.ev_done);
+    }
     if (b->ev_match) hipEventDestroy(b->ev_match);
-    if (b->ev_geo) hipEventDestroy(b->ev_geo);
+    if (b->stream_copy) hipStreamDestroy(b->stream_copy);
     delete b;
 }
 
@@ -913,48 +1003,64 @@ extern "C" int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, siz
     VO_HIP(hipSetDevice(b->ctx->device));
     VO_TRY(stage_frame(b, 2 * pair, img1, step1));
     VO_TRY(stage_frame(b, 2 * pair + 1, img2, step2));
-    init_state(b->h_state[pair], 0, K);
-    b->state_dirty = true;
+    init_state(b->h_init[pair], 0, K);
     return VO_OK;
 }
 
 extern "C" int vo_batch_set_k(vo_batch* b, int pair, const double K[9]) {
     if (!b || b->is_seq || pair < 0 || pair >= b->n_pairs || !K) return VO_ERR_INVALID_ARG;
-    init_state(b->h_state[pair], 0, K);
-    b->state_dirty = true;
+    init_state(b->h_init[pair], 0, K);
     return VO_OK;
 }
 
 extern "C" int vo_batch_run(vo_batch* b) {
     if (!b) return VO_ERR_INVALID_ARG;
     vo_ctx* ctx = b->ctx;
+    for (const PairState& S : b->h_init)  // a pair whose K was never given would divide by zero on the device
+        if (S.K[0] == 0.0 || S.K[4] == 0.0) return VO_ERR_INVALID_ARG;
     VO_HIP(hipSetDevice(ctx->device));
-    if (b->state_dirty) {  // frames were uploaded since the last run
-        VO_HIP(hipEventRecord(b->ev_upload, ctx->stream));
-        b->upload_pending = true;
+    RunHost& rh = b->rh[b->runs & 1];
+    // snapshot of K / initial pose (identity: every run starts every pair from R = I, t = 0, whatever the previous run left)
+    // and of the pair -> frame map; the upload issued from this memory two runs ago has to be over
+    if (rh.state_pending) {
+        VO_HIP(hipEventSynchronize(rh.ev_state));
+        rh.state_pending = false;
     }
+    std::memcpy(rh.init, b->h_init.data(), b->h_init.size() * sizeof(PairState));
+    std::memcpy(rh.frames, b->h_frames.data(), b->h_frames.size() * sizeof(int2));
+    if (b->n_staged > 0) {  // frames were staged since the latest run: this run reads the other slot
+        const int s = b->fill_slot;
+        if (b->cur_slot >= 0 && b->n_staged < b->n_frames)  // frames that were not replaced carry over
+            for (int f = 0; f < b->n_frames; f++)
+                if (!b->staged[f])
+                    VO_HIP(hipMemcpyAsync(b->d_img[s] + (size_t)f * b->fs.img_stride(), b->d_img[b->cur_slot] + (size_t)f * b->fs.img_stride(),
+                                          b->fs.img_stride(), hipMemcpyDeviceToDevice, b->stream_copy));
+        VO_HIP(hipEventRecord(b->ev_h2d[s], b->stream_copy));
+        b->h2d_pending[s] = true;
+        VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_h2d[s], 0));
+        b->cur_slot = s;
+        b->fill_slot = s ^ 1;
+        b->n_staged = 0;
+        std::fill(b->staged.begin(), b->staged.end(), 0);
+    }
+    if (b->cur_slot < 0) {
+        b->cur_slot = 0;
+        b->fill_slot = 1;
+    }
+    b->fs.img = b->d_img[b->cur_slot];
     VO_TRY(reset_counters(ctx, b->fs));
-    // The geometry of the previous run may still be working on this batch's pair buffers on the geometry stream: detection
-    // and description (frame buffers only) start right away, everything that writes pair buffers waits for it.
-    bool waited_geo = !b->geo_pending;
-    if (!waited_geo && (b->frames_dirty || b->state_dirty)) {
-        VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_geo, 0));
-        waited_geo = true;
-    }
-    if (b->frames_dirty) {
-        VO_HIP(hipMemcpyAsync(b->ps.frames, b->h_frames.data(), b->h_frames.size() * sizeof(int2), hipMemcpyHostToDevice,
-                              ctx->stream));
-        b->frames_dirty = false;
-    }
-    if (b->state_dirty) {
-        // K / initial pose of every pair; the kernels reset everything else themselves
-        b->h_init = b->h_state;
-        VO_HIP(hipMemcpyAsync(b->ps.st, b->h_init.data(), b->h_init.size() * sizeof(PairState), hipMemcpyHostToDevice, ctx->stream));
-        b->state_dirty = false;
-    }
     VO_TRY(vo_enqueue_detect(ctx, b->fs, true));
-    if (!waited_geo) VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_geo, 0));
+    VO_HIP(hipEventRecord(b->ev_img_free[b->cur_slot], ctx->stream));
+    b->img_free_pending[b->cur_slot] = true;
+    // The geometry of the previous run may still be working on this batch's pair buffers on the geometry stream: detection
+    // and description (frame buffers only) have started already, everything that writes pair buffers waits for it.
+    if (b->runs > 0) VO_HIP(hipStreamWaitEvent(ctx->stream, b->rh[(b->runs - 1) & 1].ev_done, 0));
+    VO_HIP(hipMemcpyAsync(b->ps.frames, rh.frames, (size_t)b->n_pairs * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(b->ps.st, rh.init, (size_t)b->n_pairs * sizeof(PairState), hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipEventRecord(rh.ev_state, ctx->stream));
+    rh.state_pending = true;
     VO_TRY(vo_enqueue_match(ctx, b->fs, b->ps, true));
+    VO_HIP(hipMemcpyAsync(rh.cnt, b->fs.cnt, (size_t)b->n_frames * sizeof(FrameCounters), hipMemcpyDeviceToHost, ctx->stream));
     // RANSAC, pose and triangulation are a few single-wavefront kernels (~1.6 ms of mostly idle GPU per step): they go to the
     // geometry stream, where they run under the detection of whatever the main stream does next
     VO_HIP(hipEventRecord(b->ev_match, ctx->stream));
@@ -965,47 +1071,41 @@ extern "C" int vo_batch_run(vo_batch* b) {
     o.max_iters = ctx->prm.ransac_max_iters;
     o.seed = ctx->prm.ransac_seed;
     o.dist_thresh = ctx->prm.distance_threshold;
-    int st_geo;
-    {
-        hipStream_t main_stream = ctx->stream;
-        ctx->stream = ctx->stream_geo;  // the launchers and stage timers of vo_geometry.hip use ctx->stream
-        st_geo = vo_enqueue_geometry(ctx, b->ps, o);
-        ctx->stream = main_stream;
-    }
-    VO_TRY(st_geo);
-    VO_HIP(hipEventRecord(b->ev_geo, ctx->stream_geo));
-    b->geo_pending = true;
-    b->fetched = false;
+    VO_TRY(vo_enqueue_geometry(ctx, b->ps, o, ctx->stream_geo));
+    // the result records travel with the run: they are on the host when ev_done fires
+    VO_HIP(hipMemcpyAsync(rh.res, b->ps.st, (size_t)b->n_pairs * sizeof(PairState), hipMemcpyDeviceToHost, ctx->stream_geo));
+    VO_HIP(hipEventRecord(rh.ev_done, ctx->stream_geo));
+    b->runs++;
     return VO_OK;
 }
 
 extern "C" int vo_batch_sync(vo_batch* b) {
     if (!b) return VO_ERR_INVALID_ARG;
     VO_HIP(hipSetDevice(b->ctx->device));
+    VO_HIP(hipStreamSynchronize(b->stream_copy));
     VO_HIP(hipStreamSynchronize(b->ctx->stream));
-    if (b->geo_pending) VO_HIP(hipEventSynchronize(b->ev_geo));
+    if (b->runs > 0) VO_HIP(hipEventSynchronize(b->rh[(b->runs - 1) & 1].ev_done));
     return VO_OK;
 }
 
-static int batch_fetch(vo_batch* b) {
-    if (b->fetched) return VO_OK;
-    vo_ctx* ctx = b->ctx;
-    if (b->geo_pending) VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_geo, 0));
-    VO_HIP(hipMemcpyAsync(b->h_state.data(), b->ps.st, b->h_state.size() * sizeof(PairState), hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(hipMemcpyAsync(b->h_cnt.data(), b->fs.cnt, b->h_cnt.size() * sizeof(FrameCounters), hipMemcpyDeviceToHost, ctx->stream));
-    VO_HIP(hipStreamSynchronize(ctx->stream));
-    b->fetched = true;
+// records of the latest run (age 0) or the one before it (age 1): waits for that run only
+static int run_records(vo_batch* b, int age, RunHost** out) {
+    if (age < 0 || age > 1 || b->runs - 1 - age < 0) return VO_ERR_INVALID_ARG;
+    RunHost& rh = b->rh[(b->runs - 1 - age) & 1];
+    VO_HIP(hipEventSynchronize(rh.ev_done));
+    *out = &rh;
     return VO_OK;
 }
 
-extern "C" int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out) {
+extern "C" int vo_batch_get_run(vo_batch* b, int age, int pair, vo_pair_out* out) {
     if (!b || !out || pair < 0 || pair >= b->n_pairs) return VO_ERR_INVALID_ARG;
     VO_HIP(hipSetDevice(b->ctx->device));
-    VO_TRY(batch_fetch(b));
-    const PairState& S = b->h_state[pair];
+    RunHost* rh = nullptr;
+    VO_TRY(run_records(b, age, &rh));
+    const PairState& S = rh->res[pair];
     std::memset(out, 0, sizeof(*out));
-    out->n_kp1 = b->h_cnt[b->h_frames[pair].x].n_raw;
-    out->n_kp2 = b->h_cnt[b->h_frames[pair].y].n_raw;
+    out->n_kp1 = rh->cnt[rh->frames[pair].x].n_raw;
+    out->n_kp2 = rh->cnt[rh->frames[pair].y].n_raw;
     out->n_match = S.n_match;
     out->status = S.status;
     if (out->n_kp1 > b->fs.cap || out->n_kp2 > b->fs.cap || S.n_match > b->ps.match_cap) out->status = VO_ERR_CAPACITY;
@@ -1020,13 +1120,16 @@ extern "C" int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out) {
     return VO_OK;
 }
 
+extern "C" int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out) { return vo_batch_get_run(b, 0, pair, out); }
+
 extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask, int cap,
                                    double* Xk, int cap_world) {
     if (!b || pair < 0 || pair >= b->n_pairs || cap < 0 || cap_world < 0) return VO_ERR_INVALID_ARG;
     vo_ctx* ctx = b->ctx;
     VO_HIP(hipSetDevice(ctx->device));
-    VO_TRY(batch_fetch(b));
-    const PairState& S = b->h_state[pair];
+    RunHost* rh = nullptr;
+    VO_TRY(run_records(b, 0, &rh));  // the bulk arrays on the device are those of the latest run, and it has finished
+    const PairState& S = rh->res[pair];
     const PairSet& ps = b->ps;
     const size_t mc = ps.match_cap;
     const int nm = std::min(S.n_used, (int)mc);

@@ -12,6 +12,7 @@
 
 // ---------------------------------------------------------------- errors
 void vo_set_hip_error(const char* what, hipError_t e, const char* file, int line);
+void vo_set_error_text(const char* text);  // what vo_last_hip_error() returns next (errors that are not HIP's)
 #define VO_HIP(call)                                             \
     do {                                                         \
         hipError_t e_ = (call);                                  \
@@ -192,7 +193,14 @@ struct vo_ctx {
     DetectTables* d_tables = nullptr;
     void* d_win_cell = nullptr;     // INTER_AREA decimation tables of every window size (vo_detect.hip: CellTab [769][21 + 1])
     void* d_win_pix = nullptr;      // PixTab [769][768]
-    uint32_t* d_rng_raw = nullptr;  // unused placeholder (rng stream is generated on device)
+    // cv::RNG streams of the registrator, one device table per seed seen by THIS context (never shared between contexts:
+    // a table is written once, before anything reads it, so streams of one context can use different seeds side by side)
+    struct RngTable {
+        uint64_t seed;
+        uint32_t* d_raw;
+    };
+    std::vector<RngTable> rng_tables;
+    int* d_signs = nullptr;         // 36 sign bits of JacobiSVD's completion vectors (vo_geometry.hip)
     bool profiling = false;
     int force_seq_describe = 0;     // vo_debug_set key 0
     int match_fp32 = 0;             // vo_debug_set key 2: shortlist on the FP32 MFMA (v_mfma_f32_32x32x2_f32) instead of split bf16
@@ -213,24 +221,44 @@ struct vo_ctx {
     size_t h_down_bytes = 0;
 };
 
+// Host-side memory of one run of a batch, pinned: what the run uploads (a snapshot of the pairs' K / initial pose and of the
+// pair -> frame map, taken when vo_batch_run is called) and what it brings back.  A batch keeps two, used alternately, so
+// that the host can prepare and enqueue run k + 1 while run k is executing, and read run k's records while k + 1 runs.
+struct RunHost {
+    PairState* init = nullptr;     // [n_pairs]
+    int2* frames = nullptr;        // [n_pairs]
+    PairState* res = nullptr;      // [n_pairs] device state after the run
+    FrameCounters* cnt = nullptr;  // [n_frames]
+    hipEvent_t ev_state = nullptr; // the upload of init / frames has finished (main stream)
+    hipEvent_t ev_done = nullptr;  // geometry finished and res / cnt are on the host (geometry stream)
+    bool state_pending = false;
+};
+
 struct vo_batch {
     vo_ctx* ctx = nullptr;
     int n_pairs = 0, rows = 0, cols = 0;
-    FrameSet fs;  // 2 * n_pairs frames: frame 2p = img1 of pair p, 2p+1 = img2
-    PairSet ps;
-    std::vector<PairState> h_state, h_init;  // host mirrors (results / initial K and pose)
-    std::vector<FrameCounters> h_cnt;
-    bool state_dirty = true, fetched = false;
     int n_frames = 0;                // frames held (2 * n_pairs for a pair batch, n_pairs + 1 for a sequence)
     bool is_seq = false;
-    std::vector<int2> h_frames;      // host copy of ps.frames
-    bool frames_dirty = false;
-    uint8_t* h_stage = nullptr;      // pinned staging copy of the frames: vo_batch_set_pair returns before the H2D copy ends
-    hipEvent_t ev_upload = nullptr;  // recorded after the latest frame upload
+    FrameSet fs;  // pair batch: frame 2p = img1 of pair p, 2p+1 = img2.  fs.img points at the frame slot the current run reads
+    PairSet ps;
+    std::vector<PairState> h_init;   // K and initial pose of every pair as the setters left them (pageable; snapshot per run)
+    std::vector<int2> h_frames;      // pair -> (query frame, train frame)
+    // Frame slots: the frames exist twice on the device (and in pinned staging memory).  The setters write the slot the
+    // latest run does NOT read and upload it on the copy stream, so the transfer of the next step's frames runs beside the
+    // kernels of the current one; vo_batch_run flips the slots when anything was staged.
+    uint8_t* d_img[2] = {nullptr, nullptr};
+    uint8_t* h_stage[2] = {nullptr, nullptr};
+    hipStream_t stream_copy = nullptr;
+    hipEvent_t ev_h2d[2] = {nullptr, nullptr};       // every upload into the slot issued so far has finished (copy stream)
+    hipEvent_t ev_img_free[2] = {nullptr, nullptr};  // the run that read the slot is past detection + description (main stream)
+    bool h2d_pending[2] = {false, false}, img_free_pending[2] = {false, false};
+    int cur_slot = -1;               // slot the latest run read (-1: no run yet)
+    int fill_slot = 0;               // slot the setters write
+    int n_staged = 0;                // distinct frames staged into fill_slot since the latest run
+    std::vector<uint8_t> staged;     // [n_frames]
+    RunHost rh[2];
+    int64_t runs = 0;                // runs enqueued so far; run k uses rh[k & 1]
     hipEvent_t ev_match = nullptr;   // matcher of the latest run finished (main stream)
-    hipEvent_t ev_geo = nullptr;     // geometry of the latest run finished (geometry stream)
-    bool geo_pending = false;
-    bool upload_pending = false;
 };
 
 // ---------------------------------------------------------------- helpers (vo_api.cpp)
@@ -239,12 +267,16 @@ void vo_frameset_free(FrameSet& fs);
 int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp);
 void vo_pairset_free(PairSet& ps);
 int vo_ctx_tmp(vo_ctx* ctx, size_t bytes, void** out);
+// device address of frame `frame` in the slot the NEXT vo_batch_run will read; marks the frame as staged (vo_prep_to_batch
+// writes there with kernels on the context's main stream)
+int vo_batch_frame_slot(vo_batch* b, int frame, uint8_t** d_dst);
 
 struct StageScope {  // records HIP events around a stage when profiling is on
     vo_ctx* ctx;
     int stage;
+    hipStream_t stream;
     hipEvent_t a = nullptr, b = nullptr;
-    StageScope(vo_ctx* c, int s);
+    StageScope(vo_ctx* c, int s, hipStream_t on = nullptr);  // on = nullptr: the context's main stream
     ~StageScope();
 };
 
@@ -254,6 +286,7 @@ void vo_build_detect_tables(DetectTables& t, int sum_cols_unused);
 int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs);
 int vo_enqueue_hessian_layer(vo_ctx* ctx, FrameSet& fs, int frame, int octave, int layer, float* d_det, float* d_trace);
 int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe);
+int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_det);
 // vo_match.hip
 int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter);
 // vo_geometry.hip
@@ -264,7 +297,8 @@ struct GeoOptions {
     int max_iters = 1000;
     uint64_t seed = (uint64_t)-1;
 };
-int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o);
+// every launch goes to `stream` (the context's main stream for the single-call entry points, its geometry stream for a batch)
+int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o, hipStream_t stream);
 int vo_enqueue_five_point(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n_hyp, const int* d_tuples,
                           double* d_E, int* d_nm);
 int vo_enqueue_sampson_masks(vo_ctx* ctx, const double* d_m1, const double* d_m2, int n, float thr_sq, const double* d_E,
@@ -275,3 +309,5 @@ int vo_enqueue_normalise(vo_ctx* ctx, PairSet& ps, double thr_px);
 int vo_upload_detect_tables(const DetectTables& t);
 int vo_build_window_tables(vo_ctx* ctx);
 int vo_geometry_init(vo_ctx* ctx);
+void vo_geometry_release(vo_ctx* ctx);
+int vo_detect_init(vo_ctx* ctx);  // per-device kernel attributes (called with the context's device current)

@@ -422,10 +422,24 @@ constexpr int kNmsQueue = 768;  // entries: strict 3 x 3 maxima cannot be neighb
 template <int TI, int DP, int PLANE>
 __device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o, int ty, int tx, int H, int W, float thr,
                                          const int32_t* __restrict__ sum, vo_keypoint* __restrict__ kps, int cap,
-                                         FrameCounters* __restrict__ cnt_frame, int filter_invalid) {
+                                         FrameCounters* __restrict__ cnt_frame, int filter_invalid,
+                                         float* __restrict__ dbg_det) {
     const int tid = threadIdx.x, lane = tid & 63, NT = blockDim.x;
     const int step = 1 << o, sw = W + 1;
     const int lrows = H / step, lcols = W / step;
+    if (dbg_det) {
+        // inspection (vo_hessian_product_det): the det planes exactly as the NMS below reads them, interior of this tile, all
+        // five layers of the octave; planes packed layer after layer, [H >> o][W >> o] each.  Null in every product launch.
+        size_t off = 0;
+        for (int q = 0; q < o; q++) off += (size_t)kLayersPerOctave * (H >> q) * (W >> q);
+        for (int s = tid; s < TI * TI; s += NT) {
+            const int yy = s / TI, xx = s - yy * TI;
+            const int i = ty * TI + yy, j = tx * TI + xx;
+            if (i < lrows && j < lcols)
+                for (int l = 0; l < kLayersPerOctave; l++)
+                    dbg_det[off + ((size_t)l * lrows + i) * lcols + j] = s_det[l * PLANE + (yy + 1) * DP + (xx + 1)];
+        }
+    }
     if (tid == 0) s_queue[0] = 0;
     __syncthreads();
     for (int l = 1; l <= 3; l++) {
@@ -540,7 +554,8 @@ constexpr int kGlobalTileLds = kGlobalTileDet + (kNmsQueue + 1) * 4;
 __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int b, int frame,
                                                         const int32_t* __restrict__ sum_base, size_t sum_stride,
                                                         const DetectGeom& g, float thr, vo_keypoint* __restrict__ kp_base,
-                                                        int cap, FrameCounters* __restrict__ cnt, int filter_invalid) {
+                                                        int cap, FrameCounters* __restrict__ cnt, int filter_invalid,
+                                                        float* __restrict__ dbg_det) {
     float (*s_det)[kHY][kHP] = reinterpret_cast<float (*)[kHY][kHP]>(smem);
     int o = 0;
 #pragma unroll
@@ -575,7 +590,7 @@ __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int
     __syncthreads();
 
     nms_tile<kTX, kHP, kHY * kHP>(&s_det[0][0][0], reinterpret_cast<int*>(smem + kGlobalTileDet), o, ty, tx, H, W, thr, sum,
-                                  kp_base + (size_t)frame * cap, cap, cnt + frame, filter_invalid);
+                                  kp_base + (size_t)frame * cap, cap, cnt + frame, filter_invalid, frame == 0 ? dbg_det : nullptr);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -615,7 +630,8 @@ template <int T, int O, int NTH>
 __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b, int frame,
                                                      const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                      int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
-                                                     FrameCounters* __restrict__ cnt, int filter_invalid) {
+                                                     FrameCounters* __restrict__ cnt, int filter_invalid,
+                                                     float* __restrict__ dbg_det) {
     using C = LdsTileCfg<T, O>;
     constexpr int TI = C::TI, step = C::step, kMarginMax = C::kMarginMax, PE = C::PE, HALF = C::HALF, PP = C::PP, DP = C::DP;
     int32_t* s_sum = reinterpret_cast<int32_t*>(smem);
@@ -722,7 +738,7 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
 
     // the candidate queue sits behind the det planes
     nms_tile<TI, DP, T * DP>(&s_det[0][0][0], reinterpret_cast<int*>(smem + C::kDetBytes), o, ty, tx, H, W, thr, sum, kp_base + (size_t)frame * cap,
-                             cap, cnt + frame, filter_invalid);
+                             cap, cnt + frame, filter_invalid, frame == 0 ? dbg_det : nullptr);
 }
 
 // octave-0 tiles (LDS patch) and the few tiles of octaves >= OG (taps from L1/L2) in ONE grid, so that the long,
@@ -731,26 +747,28 @@ template <int T0, int NTH>
 __global__ __launch_bounds__(NTH) void k_hessian_nms_fused(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                            int tiles_x0, int n_tiles0, DetectGeom g_rest, float thr,
                                                            vo_keypoint* __restrict__ kp_base, int cap,
-                                                           FrameCounters* __restrict__ cnt, int filter_invalid) {
+                                                           FrameCounters* __restrict__ cnt, int filter_invalid,
+                                                           float* __restrict__ dbg_det) {
     constexpr int kBytes = LdsTileCfg<T0, 0>::kBytes > kGlobalTileLds ? LdsTileCfg<T0, 0>::kBytes : kGlobalTileLds;
     __shared__ __attribute__((aligned(16))) unsigned char smem[kBytes];
     const int b = blockIdx.x, frame = blockIdx.y;
     // coarse tiles first in the grid: they are the long ones
     const int n_rest = g_rest.tile_base[kNumOctaves];
     if (b < n_rest)
-        hessian_nms_global_tile(smem, b, frame, sum_base, sum_stride, g_rest, thr, kp_base, cap, cnt, filter_invalid);
+        hessian_nms_global_tile(smem, b, frame, sum_base, sum_stride, g_rest, thr, kp_base, cap, cnt, filter_invalid, dbg_det);
     else
         hessian_nms_lds_tile<T0, 0, NTH>(smem, b - n_rest, frame, sum_base, sum_stride, H, W, tiles_x0, thr, kp_base, cap, cnt,
-                                    filter_invalid);
+                                    filter_invalid, dbg_det);
 }
 
 template <int T, int O, int NTH>
 __global__ __launch_bounds__(NTH) void k_hessian_nms_lds(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                          int tiles_x, float thr, vo_keypoint* __restrict__ kp_base, int cap,
-                                                         FrameCounters* __restrict__ cnt, int filter_invalid) {
+                                                         FrameCounters* __restrict__ cnt, int filter_invalid,
+                                                         float* __restrict__ dbg_det) {
     __shared__ __attribute__((aligned(16))) unsigned char smem[LdsTileCfg<T, O>::kBytes];
     hessian_nms_lds_tile<T, O, NTH>(smem, blockIdx.x, blockIdx.y, sum_base, sum_stride, H, W, tiles_x, thr, kp_base, cap, cnt,
-                               filter_invalid);
+                               filter_invalid, dbg_det);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1967,8 +1985,9 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const vo_keypoint* __r
 // ------------------------------------------------------------------------------------------------
 // host: whole detect (+describe) pipeline for a frame set
 // ------------------------------------------------------------------------------------------------
-int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
-    VO_TRY(vo_enqueue_integral(ctx, fs));
+// a2 + a3 of the product path: the two fused Hessian + NMS launches.  dbg_det (inspection only, otherwise null) receives the
+// det planes of frame 0 as the NMS reads them.
+int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_det) {
     DetectGeom g;
     g.H = fs.H;
     g.W = fs.W;
@@ -2004,14 +2023,14 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         }
         StageScope* sc1 = new StageScope(ctx, ST_HESSIAN_OCT1);
         hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1, 512>), dim3(tx1 * ty1, fs.F), dim3(512), 0, s_oct1, fs.sum, fs.sum_stride(),
-                           fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0);
+                           fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0, dbg_det);
         delete sc1;
         {
             StageScope sc0(ctx, ST_HESSIAN_OCT0);
             const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
             hipLaunchKernelGGL((k_hessian_nms_fused<T0, 256>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
                                fs.sum_stride(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
-                               describe ? 1 : 0);
+                               describe ? 1 : 0, dbg_det);
         }
         if (beside) {
             VO_HIP(hipEventRecord(ctx->ev_join, ctx->stream_aux));
@@ -2019,6 +2038,12 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
         }
         VO_HIP(hipGetLastError());
     }
+    return VO_OK;
+}
+
+int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
+    VO_TRY(vo_enqueue_integral(ctx, fs));
+    VO_TRY(vo_enqueue_hessian_nms(ctx, fs, describe, nullptr));
     {
         StageScope sc(ctx, ST_SORT);
         hipLaunchKernelGGL(k_count_clamp, dim3((fs.F + 255) / 256), dim3(256), 0, ctx->stream, fs.cnt, fs.cap, fs.F);
@@ -2027,12 +2052,6 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             int np = 1024;
             while (np < fs.cap) np <<= 1;
             const size_t lds = (size_t)np * sizeof(unsigned long long);
-            static bool attr_set = false;  // > 64 KB of dynamic LDS needs the attribute once per process
-            if (!attr_set) {
-                VO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_bitonic), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           kBitonicMax * (int)sizeof(unsigned long long)));
-                attr_set = true;
-            }
             hipLaunchKernelGGL(k_sort_bitonic, dim3(fs.F), dim3(1024), lds, ctx->stream, fs.kp_raw, fs.cap, fs.cnt, fs.kp);
         } else {
             dim3 gr((fs.cap + 255) / 256, (fs.cap + kRankChunk - 1) / kRankChunk, fs.F);
@@ -2102,6 +2121,15 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
             VO_HIP(hipGetLastError());
         }
     }
+    return VO_OK;
+}
+
+// > 64 KB of dynamic LDS needs the opt-in, and the attribute belongs to the DEVICE's copy of the kernel: set for every context
+// (vo_ctx_create, with the context's device current), not once per process
+int vo_detect_init(vo_ctx* ctx) {
+    (void)ctx;
+    VO_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(k_sort_bitonic), hipFuncAttributeMaxDynamicSharedMemorySize,
+                               kBitonicMax * (int)sizeof(unsigned long long)));
     return VO_OK;
 }
 

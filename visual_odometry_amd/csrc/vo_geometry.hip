@@ -1305,14 +1305,8 @@ __global__ __launch_bounds__(256) void k_sampson_masks(const double* __restrict_
 // ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
-struct GeoGlobals {
-    int* d_signs = nullptr;       // 36 sign bits of JacobiSVD's completion vectors
-    uint32_t* d_raw = nullptr;    // cv::RNG stream
-    int raw_len = 0;
-    uint64_t raw_seed = 0;
-    bool have_raw = false;
-};
-static GeoGlobals g_geo[16];
+constexpr int kRawLen = kMaxHyp * 16 + 4096;  // 32-bit draws kept of a cv::RNG stream
+constexpr size_t kMaxRngTables = 8;           // seeds a context keeps resident
 
 static inline uint32_t rng_next(uint64_t& state) {
     state = (uint64_t)(uint32_t)state * 4164903690U + (uint32_t)(state >> 32);
@@ -1320,31 +1314,52 @@ static inline uint32_t rng_next(uint64_t& state) {
 }
 
 int vo_geometry_init(vo_ctx* ctx) {
-    GeoGlobals& G = g_geo[ctx->device & 15];
-    if (!G.d_signs) {
-        int signs[36];
-        uint64_t s = 0x12345678;
-        for (int i = 0; i < 36; i++) signs[i] = (rng_next(s) & 256) != 0 ? 1 : 0;
-        VO_HIP(hipMalloc((void**)&G.d_signs, sizeof(signs)));
-        VO_HIP(hipMemcpy(G.d_signs, signs, sizeof(signs), hipMemcpyHostToDevice));
-    }
-    if (!G.d_raw) {
-        G.raw_len = kMaxHyp * 16 + 4096;
-        VO_HIP(hipMalloc((void**)&G.d_raw, (size_t)G.raw_len * sizeof(uint32_t)));
-    }
+    int signs[36];
+    uint64_t s = 0x12345678;
+    for (int i = 0; i < 36; i++) signs[i] = (rng_next(s) & 256) != 0 ? 1 : 0;
+    VO_HIP(hipMalloc((void**)&ctx->d_signs, sizeof(signs)));
+    VO_HIP(hipMemcpy(ctx->d_signs, signs, sizeof(signs), hipMemcpyHostToDevice));
     return VO_OK;
 }
 
-static int ensure_raw(vo_ctx* ctx, uint64_t seed) {
-    GeoGlobals& G = g_geo[ctx->device & 15];
-    if (G.have_raw && G.raw_seed == seed) return VO_OK;
-    std::vector<uint32_t> raw(G.raw_len);
+void vo_geometry_release(vo_ctx* ctx) {
+    if (ctx->d_signs) hipFree(ctx->d_signs);
+    ctx->d_signs = nullptr;
+    for (auto& t : ctx->rng_tables)
+        if (t.d_raw) hipFree(t.d_raw);
+    ctx->rng_tables.clear();
+}
+
+// Device table of the cv::RNG stream for `seed`.  Tables belong to the context and are written exactly once, by a blocking
+// copy into memory nothing has read yet - so a batch whose geometry is still in flight on the geometry stream keeps reading
+// ITS seed's table while a single call (or another batch) asks for a different seed.  Only when a context has used more
+// than kMaxRngTables seeds is the oldest table recycled, after all three streams of the context have drained.
+static int rng_table(vo_ctx* ctx, uint64_t seed, const uint32_t** out) {
+    for (auto& t : ctx->rng_tables)
+        if (t.seed == seed) {
+            *out = t.d_raw;
+            return VO_OK;
+        }
+    std::vector<uint32_t> raw(kRawLen);
     uint64_t s = seed ? seed : 0xffffffffULL;  // cv::RNG(0) falls back to 0xffffffff
-    for (int i = 0; i < G.raw_len; i++) raw[i] = rng_next(s);
-    VO_HIP(hipStreamSynchronize(ctx->stream));
-    VO_HIP(hipMemcpy(G.d_raw, raw.data(), raw.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
-    G.raw_seed = seed;
-    G.have_raw = true;
+    for (int i = 0; i < kRawLen; i++) raw[i] = rng_next(s);
+    vo_ctx::RngTable t{seed, nullptr};
+    if (ctx->rng_tables.size() >= kMaxRngTables) {
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+        VO_HIP(hipStreamSynchronize(ctx->stream_geo));
+        VO_HIP(hipStreamSynchronize(ctx->stream_aux));
+        t.d_raw = ctx->rng_tables.front().d_raw;
+        ctx->rng_tables.erase(ctx->rng_tables.begin());
+    } else {
+        VO_HIP(hipMalloc((void**)&t.d_raw, raw.size() * sizeof(uint32_t)));
+    }
+    if (hipMemcpy(t.d_raw, raw.data(), raw.size() * sizeof(uint32_t), hipMemcpyHostToDevice) != hipSuccess) {
+        vo_set_hip_error("hipMemcpy(rng table)", hipGetLastError(), __FILE__, __LINE__);
+        hipFree(t.d_raw);
+        return VO_ERR_HIP;
+    }
+    ctx->rng_tables.push_back(t);
+    *out = t.d_raw;
     return VO_OK;
 }
 
@@ -1371,16 +1386,16 @@ static float thr_sq_of(double thr_px, const double K[9]) {
 // RANSAC (optional) -> pose (optional) -> triangPoints (optional) for every pair of the set.
 // The K used for the threshold is the same for all pairs of a set when called from the batch API
 // with differing intrinsics the threshold is taken per pair on the device.
-int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o) {
-    GeoGlobals& G = g_geo[ctx->device & 15];
+int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o, hipStream_t stream) {
     const int P = ps.P, mc = ps.match_cap;
     if (o.run_ransac) {
-        VO_TRY(ensure_raw(ctx, o.seed));
+        const uint32_t* d_raw = nullptr;
+        VO_TRY(rng_table(ctx, o.seed, &d_raw));
         {
-            StageScope sc(ctx, ST_RANSAC_SAMPLE);
-            hipLaunchKernelGGL(k_geo_prep, dim3((mc + 255) / 256, P), dim3(256), 0, ctx->stream, ps.p1, ps.p2, mc, ps.m1,
+            StageScope sc(ctx, ST_RANSAC_SAMPLE, stream);
+            hipLaunchKernelGGL(k_geo_prep, dim3((mc + 255) / 256, P), dim3(256), 0, stream, ps.p1, ps.p2, mc, ps.m1,
                                ps.m2, ps.st, o.max_iters, o.thr_px, 1);
-            hipLaunchKernelGGL(k_ransac_tuples, dim3(P), dim3(64), 0, ctx->stream, G.d_raw, G.raw_len, ps.st, ps.max_hyp,
+            hipLaunchKernelGGL(k_ransac_tuples, dim3(P), dim3(64), 0, stream, d_raw, kRawLen, ps.st, ps.max_hyp,
                                ps.tuples);
             VO_HIP(hipGetLastError());
         }
@@ -1389,40 +1404,40 @@ int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o) {
             const int h0 = bounds[c], h1 = std::min(bounds[c + 1], o.max_iters);
             if (h0 >= h1) break;
             {
-                StageScope sc(ctx, ST_RANSAC_SOLVE_SCORE);
-                hipLaunchKernelGGL(k_ransac_hyp, dim3(h1 - h0, P), dim3(64), 0, ctx->stream, ps.m1, ps.m2, mc, ps.tuples,
-                                   ps.max_hyp, h0, h1, ps.st, G.d_signs, ps.models,
+                StageScope sc(ctx, ST_RANSAC_SOLVE_SCORE, stream);
+                hipLaunchKernelGGL(k_ransac_hyp, dim3(h1 - h0, P), dim3(64), 0, stream, ps.m1, ps.m2, mc, ps.tuples,
+                                   ps.max_hyp, h0, h1, ps.st, ctx->d_signs, ps.models,
                                    ps.nmodels, ps.counts);
                 VO_HIP(hipGetLastError());
             }
             {
-                StageScope sc(ctx, ST_RANSAC_SELECT);
-                hipLaunchKernelGGL(k_ransac_scan, dim3(P), dim3(64), 0, ctx->stream, ps.st, ps.max_hyp, h1, o.prob,
+                StageScope sc(ctx, ST_RANSAC_SELECT, stream);
+                hipLaunchKernelGGL(k_ransac_scan, dim3(P), dim3(64), 0, stream, ps.st, ps.max_hyp, h1, o.prob,
                                    ps.nmodels, ps.counts);
                 VO_HIP(hipGetLastError());
             }
         }
         {
-            StageScope sc(ctx, ST_RANSAC_SELECT);
-            hipLaunchKernelGGL(k_ransac_finish, dim3(P), dim3(1024), 0, ctx->stream, ps.st, ps.max_hyp, mc, ps.m1, ps.m2,
+            StageScope sc(ctx, ST_RANSAC_SELECT, stream);
+            hipLaunchKernelGGL(k_ransac_finish, dim3(P), dim3(1024), 0, stream, ps.st, ps.max_hyp, mc, ps.m1, ps.m2,
                                ps.p1, ps.p2, ps.models, ps.nmodels, ps.mask, ps.in1, ps.in2);
             VO_HIP(hipGetLastError());
         }
     }
     if (o.run_pose) {
-        StageScope sc(ctx, ST_POSE);
-        hipLaunchKernelGGL(k_pose_decompose, dim3(P), dim3(64), 0, ctx->stream, ps.st, ctx->prm.inlier_threshold,
+        StageScope sc(ctx, ST_POSE, stream);
+        hipLaunchKernelGGL(k_pose_decompose, dim3(P), dim3(64), 0, stream, ps.st, ctx->prm.inlier_threshold,
                            o.gate ? 1 : 0);
-        hipLaunchKernelGGL(k_pose_cheirality, dim3((mc + 255) / 256, P), dim3(256), 0, ctx->stream, ps.st, mc, ps.in1,
+        hipLaunchKernelGGL(k_pose_cheirality, dim3((mc + 255) / 256, P), dim3(256), 0, stream, ps.st, mc, ps.in1,
                            ps.in2, o.dist_thresh);
-        hipLaunchKernelGGL(k_pose_select, dim3(P), dim3(64), 0, ctx->stream, ps.st, ctx->prm.vpf_threshold, o.gate ? 1 : 0);
+        hipLaunchKernelGGL(k_pose_select, dim3(P), dim3(64), 0, stream, ps.st, ctx->prm.vpf_threshold, o.gate ? 1 : 0);
         VO_HIP(hipGetLastError());
     }
     if (o.run_triang) {
-        StageScope sc(ctx, ST_TRIANGULATE);
-        hipLaunchKernelGGL(k_triang, dim3((mc + 255) / 256, P), dim3(256), 0, ctx->stream, ps.st, mc, ps.in1, ps.in2,
+        StageScope sc(ctx, ST_TRIANGULATE, stream);
+        hipLaunchKernelGGL(k_triang, dim3((mc + 255) / 256, P), dim3(256), 0, stream, ps.st, mc, ps.in1, ps.in2,
                            (const double*)nullptr, 0, 1, ctx->prm.reprojection_tolerance, ps.X4, ps.Xpre, ps.flag);
-        hipLaunchKernelGGL(k_triang_filter, dim3(P), dim3(1024), 0, ctx->stream, ps.st, mc, ps.flag, ps.Xpre, ps.tmp,
+        hipLaunchKernelGGL(k_triang_filter, dim3(P), dim3(1024), 0, stream, ps.st, mc, ps.flag, ps.Xpre, ps.tmp,
                            ps.Xk);
         VO_HIP(hipGetLastError());
     }
@@ -1431,10 +1446,9 @@ int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o) {
 
 int vo_enqueue_five_point(vo_ctx* ctx, const double* d_x1, const double* d_x2, int n_hyp, const int* d_tuples,
                           double* d_E, int* d_nm) {
-    GeoGlobals& G = g_geo[ctx->device & 15];
     StageScope sc(ctx, ST_RANSAC_SOLVE_SCORE);
     hipLaunchKernelGGL(k_ransac_hyp, dim3(n_hyp, 1), dim3(64), 0, ctx->stream, d_x1, d_x2, 0, d_tuples, n_hyp, 0, n_hyp,
-                       (const PairState*)nullptr, G.d_signs, d_E, d_nm, (int*)nullptr);
+                       (const PairState*)nullptr, ctx->d_signs, d_E, d_nm, (int*)nullptr);
     VO_HIP(hipGetLastError());
     return VO_OK;
 }

@@ -624,8 +624,10 @@ extern "C" int vo_prep_to_batch(vo_prep* pp, const uint8_t* bgr, size_t step, vo
     if (b->ctx != pp->ctx || frame < 0 || frame >= b->n_frames) return VO_ERR_INVALID_ARG;
     if (b->rows != pp->p.dst_rows || b->cols != pp->p.dst_cols) return VO_ERR_INVALID_ARG;
     VO_HIP(hipSetDevice(pp->ctx->device));
-    // same stream as the batch's pipeline: the frame is in place before vo_batch_run's kernels start
-    return prep_enqueue(pp, bgr, step, b->fs.img + (size_t)frame * b->fs.img_stride(), b->cols);
+    // same stream as the batch's pipeline: the frame is in place before the kernels of the next vo_batch_run start
+    uint8_t* dst = nullptr;
+    VO_TRY(vo_batch_frame_slot(b, frame, &dst));
+    return prep_enqueue(pp, bgr, step, dst, b->cols);
 }
 
 extern "C" int vo_prep_rerun(vo_prep* pp, int reps) {

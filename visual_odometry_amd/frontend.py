@@ -105,6 +105,19 @@ class Context:
         self._chk(self.lib.vo_hessian_layer(self._h, _p(img, u8p), h, w, C.c_size_t(img.strides[0]), octave, layer, _p(det, f32p), _p(tr, f32p)))
         return det, tr
 
+    def hessian_product_det(self, img):
+        """det planes of all 20 layers as the product's fused Hessian + NMS kernels hold them: list of 20 arrays."""
+        img = _img(img)
+        h, w = img.shape
+        sizes = [((h >> o), (w >> o)) for o in range(4) for _ in range(5)]
+        flat = np.empty(sum(a * b for a, b in sizes), np.float32)
+        self._chk(self.lib.vo_hessian_product_det(self._h, _p(img, u8p), h, w, C.c_size_t(img.strides[0]), _p(flat, f32p), C.c_size_t(flat.size)))
+        out, off = [], 0
+        for a, b in sizes:
+            out.append(flat[off : off + a * b].reshape(a, b))
+            off += a * b
+        return out
+
     # ---- a1-a6
     def detect_describe(self, img, describe=True, cap=None):
         img = _img(img)
@@ -297,9 +310,10 @@ class Batch:
     def sync(self):
         self.ctx._chk(self.ctx.lib.vo_batch_sync(self._h))
 
-    def get(self, i) -> VoPairOut:
+    def get(self, i, age: int = 0) -> VoPairOut:
+        """Record of pair i of the latest run (age 0) or of the run before it (age 1, vo_batch_get_run)."""
         out = VoPairOut()
-        self.ctx._chk(self.ctx.lib.vo_batch_get(self._h, i, C.byref(out)))
+        self.ctx._chk(self.ctx.lib.vo_batch_get_run(self._h, int(age), i, C.byref(out)))
         return out
 
     def get_points(self, i, cap=None):
