@@ -176,6 +176,18 @@ int vo_triang_points(vo_ctx* ctx, const float* in1xy, const float* in2xy, int n,
                      const double R[9], const double t[3], const double K[9],
                      double* Xk, int cap, int* m);
 
+/* ---- triangPoints without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot allocate
+ * device memory - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments,
+ * results and status codes as vo_triang_points (bit-identical output), but every intermediate lives in a static device
+ * array of the library (1.77 MiB per GPU, held until the process ends) and the host staging goes through the pinned
+ * buffers vo_ctx_create made: the call issues no hipMalloc / hipFree / hipHostMalloc.  Limits: n <= VO_NOALLOC_MAX_POINTS,
+ * otherwise VO_ERR_CAPACITY (vo_last_hip_error() says so); VO_ERR_UNSUPPORTED while vo_profile_enable is on (the stage
+ * timers create events).  All contexts of one GPU share the array: calls that overlap on one GPU race.                */
+#define VO_NOALLOC_MAX_POINTS 16384
+int vo_triang_points_noalloc(vo_ctx* ctx, const float* in1xy, const float* in2xy, int n,
+                             const double R[9], const double t[3], const double K[9],
+                             double* Xk, int cap, int* m);
+
 /* ---- batched, device-resident pipeline: all pairs of a batch run through
  * detect x2 -> match -> E-RANSAC -> recoverPose -> triangulate with no host round trip.  */
 typedef struct vo_pair_out {

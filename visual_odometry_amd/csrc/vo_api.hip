@@ -194,6 +194,8 @@ int vo_ctx_tmp(vo_ctx* ctx, size_t bytes, void** out) {
     return VO_OK;
 }
 
+static int ctx_bounce(vo_ctx* ctx, size_t bytes, bool down, uint8_t** out);
+
 // ---------------------------------------------------------------- context
 extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** out) {
     if (!out) return VO_ERR_INVALID_ARG;
@@ -236,8 +238,14 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
     if (st == VO_OK) st = vo_build_window_tables(ctx);
     if (st == VO_OK) st = vo_geometry_init(ctx);
     if (st == VO_OK) st = vo_detect_init(ctx);
+    // the pinned bounce buffers exist from the start, large enough for vo_triang_points_noalloc's maximum (it may not grow them)
+    uint8_t* unused = nullptr;
+    if (st == VO_OK) st = ctx_bounce(ctx, (size_t)1 << 20, false, &unused);
+    if (st == VO_OK) st = ctx_bounce(ctx, (size_t)1 << 20, true, &unused);
     if (st != VO_OK) {
         vo_geometry_release(ctx);
+        if (ctx->h_up) hipHostFree(ctx->h_up);
+        if (ctx->h_down) hipHostFree(ctx->h_down);
         if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
         if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
         if (ctx->d_win_pix) hipFree(ctx->d_win_pix);

@@ -201,6 +201,7 @@ struct vo_ctx {
     };
     std::vector<RngTable> rng_tables;
     int* d_signs = nullptr;         // 36 sign bits of JacobiSVD's completion vectors (vo_geometry.hip)
+    unsigned char* d_noalloc = nullptr;  // this device's address of the static scratch array of vo_triang_points_noalloc
     bool profiling = false;
     int force_seq_describe = 0;     // vo_debug_set key 0
     int match_fp32 = 0;             // vo_debug_set key 2: shortlist on the FP32 MFMA (v_mfma_f32_32x32x2_f32) instead of split bf16

@@ -1313,12 +1313,37 @@ static inline uint32_t rng_next(uint64_t& state) {
     return (uint32_t)state;
 }
 
+// ---- vo_triang_points_noalloc: the one entry point that allocates nothing -------------------------------------------
+// Its kernels (k_triang, k_triang_filter) need the same intermediates as vo_triang_points' - staged inlier points, pair state
+// (counters, Z statistics), homogeneous points, pre-filter points, filter flags, compaction scratch, output rows - which that
+// entry point keeps in hipMalloc'ed pair buffers.  Here they live in this file-scope device array: one copy per GPU, held
+// until the process ends, shared by every context on that GPU (overlapping calls on one GPU race; the entry point is
+// synchronous, so calls from one thread never overlap).  In host code the array's NAME is only a handle: its device address
+// comes from hipGetSymbolAddress, once per context with the context's device current (vo_geometry_init), and that pointer -
+// never the name - is what kernels, copies and memsets are given.
+constexpr size_t kNaN = VO_NOALLOC_MAX_POINTS;
+constexpr size_t na_align(size_t v) { return (v + 255) & ~(size_t)255; }
+constexpr size_t kNaSt = 0;
+constexpr size_t kNaIn1 = kNaSt + na_align(sizeof(PairState));
+constexpr size_t kNaIn2 = kNaIn1 + na_align(kNaN * 2 * sizeof(float));
+constexpr size_t kNaX4 = kNaIn2 + na_align(kNaN * 2 * sizeof(float));
+constexpr size_t kNaXpre = kNaX4 + na_align(kNaN * 4 * sizeof(float));
+constexpr size_t kNaXk = kNaXpre + na_align(kNaN * 3 * sizeof(double));
+constexpr size_t kNaFlag = kNaXk + na_align(kNaN * 3 * sizeof(double));
+constexpr size_t kNaTmp = kNaFlag + na_align(kNaN);
+constexpr size_t kNaBytes = kNaTmp + na_align(kNaN * 4 * sizeof(double));  // 1 852 416 bytes
+static __device__ __align__(256) unsigned char scratch[kNaBytes];
+
 int vo_geometry_init(vo_ctx* ctx) {
     int signs[36];
     uint64_t s = 0x12345678;
     for (int i = 0; i < 36; i++) signs[i] = (rng_next(s) & 256) != 0 ? 1 : 0;
     VO_HIP(hipMalloc((void**)&ctx->d_signs, sizeof(signs)));
     VO_HIP(hipMemcpy(ctx->d_signs, signs, sizeof(signs), hipMemcpyHostToDevice));
+    // this device's copy of the scratch array (the caller, vo_ctx_create, has made the context's device current)
+    unsigned char* ptr = nullptr;
+    VO_HIP(hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch)));
+    ctx->d_noalloc = ptr;
     return VO_OK;
 }
 
@@ -1477,5 +1502,68 @@ int vo_enqueue_normalise(vo_ctx* ctx, PairSet& ps, double thr_px) {
     hipLaunchKernelGGL(k_geo_prep, dim3((ps.match_cap + 255) / 256, ps.P), dim3(256), 0, ctx->stream, ps.p1, ps.p2, ps.match_cap,
                        ps.m1, ps.m2, ps.st, 1, thr_px, 1);
     VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+// ---- a13-a14 without any allocation (no counterpart in the reference; see include/vo_mi355x.h) -----------------------
+extern "C" int vo_triang_points_noalloc(vo_ctx* ctx, const float* in1xy, const float* in2xy, int n, const double R[9],
+                                        const double t[3], const double K[9], double* Xk, int cap, int* m) {
+    if (!ctx || !R || !t || !K || !m || n < 0 || cap < 0 || (n > 0 && (!in1xy || !in2xy))) return VO_ERR_INVALID_ARG;
+    *m = 0;
+    if (n == 0) return VO_OK;
+    if (n > VO_NOALLOC_MAX_POINTS) {
+        char msg[160];
+        snprintf(msg, sizeof(msg), "vo_triang_points_noalloc: %d points exceed VO_NOALLOC_MAX_POINTS = %d (use vo_triang_points)", n,
+                 VO_NOALLOC_MAX_POINTS);
+        vo_set_error_text(msg);
+        return VO_ERR_CAPACITY;
+    }
+    if (ctx->profiling) return VO_ERR_UNSUPPORTED;  // the stage timers create events
+    const size_t pb = (size_t)n * 2 * sizeof(float), sb = na_align(sizeof(PairState)), wb = (size_t)n * sizeof(double);
+    // pinned bounce buffers: sized for the maximum by vo_ctx_create, never grown here
+    if (!ctx->d_noalloc || ctx->h_up_bytes < sb + 2 * pb || ctx->h_down_bytes < sb + 3 * wb) return VO_ERR_UNSUPPORTED;
+    VO_HIP(hipSetDevice(ctx->device));
+    unsigned char* d = ctx->d_noalloc;  // the device address of `scratch` on this GPU
+    PairSet v;                          // a view into the scratch array: one pair, VO_NOALLOC_MAX_POINTS matches
+    v.P = 1;
+    v.kp_cap = 64;
+    v.match_cap = (int)kNaN;
+    v.max_hyp = 0;
+    v.st = reinterpret_cast<PairState*>(d + kNaSt);
+    v.in1 = reinterpret_cast<float*>(d + kNaIn1);
+    v.in2 = reinterpret_cast<float*>(d + kNaIn2);
+    v.X4 = reinterpret_cast<float*>(d + kNaX4);
+    v.Xpre = reinterpret_cast<double*>(d + kNaXpre);
+    v.Xk = reinterpret_cast<double*>(d + kNaXk);
+    v.flag = d + kNaFlag;
+    v.tmp = reinterpret_cast<double*>(d + kNaTmp);
+    // the whole pair state is written here, so nothing of the previous call survives in it; flags, X4, Xpre, tmp and Xk are
+    // written by the kernels for [0, n) before they are read
+    PairState* S = reinterpret_cast<PairState*>(ctx->h_up);
+    std::memset(S, 0, sizeof(*S));
+    S->n_match = S->n_used = S->n_inl = n;
+    S->best_hyp = -1;
+    S->success = 1;
+    std::memcpy(S->K, K, 9 * sizeof(double));
+    std::memcpy(S->R, R, 9 * sizeof(double));
+    std::memcpy(S->t, t, 3 * sizeof(double));
+    std::memcpy(ctx->h_up + sb, in1xy, pb);
+    std::memcpy(ctx->h_up + sb + pb, in2xy, pb);
+    VO_HIP(hipMemcpyAsync(v.st, ctx->h_up, sizeof(PairState), hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(v.in1, ctx->h_up + sb, pb, hipMemcpyHostToDevice, ctx->stream));
+    VO_HIP(hipMemcpyAsync(v.in2, ctx->h_up + sb + pb, pb, hipMemcpyHostToDevice, ctx->stream));
+    GeoOptions o;
+    o.run_ransac = o.run_pose = false;
+    VO_TRY(vo_enqueue_geometry(ctx, v, o, ctx->stream));
+    // the number of points kept is known only after the kernels: bring the first n entries of every row down with the state
+    VO_HIP(hipMemcpyAsync(ctx->h_down, v.st, sizeof(PairState), hipMemcpyDeviceToHost, ctx->stream));
+    for (int r = 0; r < 3; r++)
+        VO_HIP(hipMemcpyAsync(ctx->h_down + sb + (size_t)r * wb, v.Xk + (size_t)r * kNaN, wb, hipMemcpyDeviceToHost, ctx->stream));
+    VO_HIP(hipStreamSynchronize(ctx->stream));
+    const PairState* Sd = reinterpret_cast<const PairState*>(ctx->h_down);
+    *m = Sd->n_world;
+    if (Sd->n_world > cap) return VO_ERR_CAPACITY;
+    if (Sd->n_world > 0 && Xk)
+        for (int r = 0; r < 3; r++) std::memcpy(Xk + (size_t)r * cap, ctx->h_down + sb + (size_t)r * wb, (size_t)Sd->n_world * sizeof(double));
     return VO_OK;
 }

@@ -251,6 +251,22 @@ class Context:
         self._chk(self.lib.vo_triang_points(self._h, _p(p1, f32p), _p(p2, f32p), n, _p(R, f64p), _p(t, f64p), _p(K, f64p), _p(X, f64p), cap, C.byref(m)))
         return X[:, : m.value].copy()
 
+    def triangPoints_noalloc(self, inl1, inl2, R, t, K):
+        """vo_triang_points_noalloc: triangPoints for callers that cannot allocate device memory (static device scratch,
+        at most VO_NOALLOC_MAX_POINTS points); same result as triangPoints."""
+        p1 = np.ascontiguousarray(inl1, np.float32)
+        p2 = np.ascontiguousarray(inl2, np.float32)
+        R = np.ascontiguousarray(R, np.float64)
+        t = np.ascontiguousarray(t, np.float64)
+        K = np.ascontiguousarray(K, np.float64)
+        n = len(p1)
+        cap = max(n, 1)
+        X = np.zeros((3, cap), np.float64)
+        m = C.c_int(0)
+        self._chk(self.lib.vo_triang_points_noalloc(self._h, _p(p1, f32p), _p(p2, f32p), n, _p(R, f64p), _p(t, f64p), _p(K, f64p), _p(X, f64p), cap,
+                                                    C.byref(m)))
+        return X[:, : m.value].copy()
+
     # ---- profiling
     def debug_set(self, key, value):
         """Test hooks (vo_debug_set): key 0 = force the sequential descriptor-window walk."""
