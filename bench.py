@@ -1,16 +1,22 @@
 #!/usr/bin/env python3
 """Headline benchmark: frame-pairs/s of the VO front end (2x SURF detect+describe, brute-force 2-NN + ratio,
-E-RANSAC + recoverPose, triangulation) on synthetic 1080p pairs with ~8k keypoints per frame (BASELINE config 2).
+E-RANSAC + recoverPose, triangulation) on synthetic 1080p pairs with ~8k keypoints per frame (BASELINE configs[1]).
 
-A "step" is one pass of the device-resident batch pipeline over BATCH frame pairs whose frames are already in
-HBM.  With --gpus N the pairs are sharded over N ranks (one process per GPU, no data-path collective); the
-only collective is the gather of the per-pair result records at the end (RCCL via torch.distributed).
+A "step" is one pass of the batch pipeline over BATCH frame pairs.  `value` is the SURVEY 8d metric: steady state with both
+frames of every pair uploaded from host memory in every step (pinned staging + the batch's copy stream: the upload of step
+k + 1 runs beside the kernels of step k) and the result records read back on the host.  The rate with the frames resident in
+HBM is reported beside it (`resident`).  With --gpus N the pairs are sharded over N ranks (one process per GPU, no data-path
+collective); the only collective is the gather of the per-pair result records (RCCL via torch.distributed).
+
+`python bench.py --gpus N` without a torchrun environment starts the N ranks itself (fresh child processes, before this
+process touches torch or HIP); under torchrun it is one rank.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -19,215 +25,257 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32 MFMA peak (= vector rate); the matcher no longer runs on it
+MFMA_F32_PEAK_TFLOPS = 157.3  # dense FP32 MFMA peak (= vector rate)
 MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md)
+FP64_VALU_PEAK_TFLOPS = 78.6  # vector FP64 (MI355X_MICROARCH.md)
 N_SIMD, VALU_CLOCK_HZ = 1024, 2.4e9
 SAMPLE_ISSUE_CYCLES = 86  # VALU issue cycles of one bilinear window sample per wavefront
 MFMA_EXEC_FACTOR = 25.0 / 8.0  # executed bf16 MFMA flop per algorithmic FP32 flop of the matcher (split-bf16 products + norm step)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")  # PMC passes of `bench.py --profile-region`
 
 
 def layer_samples(h, w):
     return sum(5 * (h >> o) * (w >> o) for o in range(4))
 
 
-def main():
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="frame pairs per step per GPU (resident in HBM; ~75 MB per pair)")
-    ap.add_argument("--scenes", type=int, default=4, help="distinct synthetic pairs per GPU (replicated to fill the batch)")
+    ap.add_argument("--batch", type=int, default=64, help="frame pairs per step per GPU (~75 MB of HBM per pair)")
+    ap.add_argument("--scenes", type=int, default=64, help="distinct synthetic pairs per GPU (cycled to fill the batch)")
     ap.add_argument("--matcher", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="matrix-core formulation of the matcher's contraction (fp32 = v_mfma_f32_32x32x2_f32, for A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-pairs", type=int, default=6)
-    args = ap.parse_args()
+    ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: skip the legs for the other BASELINE configs")
+    ap.add_argument("--profile-region", action="store_true",
+                    help="for rocprofv3: ONLY the per-kernel timing pass of the headline workload (every kernel alone on the main "
+                         "stream, the condition roofline.launch_ms is measured under), so that the profiler's average duration of a "
+                         "kernel is comparable with it")
+    ap.add_argument("--c3-frames", type=int, default=512)
+    return ap.parse_args()
 
-    import numpy as np
-    import torch
+
+def launch_ranks(args) -> int:
+    """--gpus N outside torchrun: start the N ranks as children of this (GPU-free) process, as the driver would."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def _scene_job(job):
+    """worker of the generation pool (fresh process, numpy only)"""
+    from visual_odometry_amd import synth
+
+    kind, seed = job
+    sc = synth.scene_c2(seed) if kind == "c2" else synth.scene_c1(seed)
+    return sc.img1, sc.img2, sc.K
+
+
+def make_inputs(args, rank, world, extras):
+    """All synthetic inputs, rendered on the host BEFORE anything initialises the GPU (the pool forks/spawns processes)."""
+    import multiprocessing as mp
+
+    from visual_odometry_amd import synth
+
+    ncpu = len(os.sched_getaffinity(0))
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", str(world)))
+    workers = max(1, min(16, int(os.environ.get("OMP_NUM_THREADS", "16")), ncpu // max(local_world, 1)))
+    jobs = [("c2", 2002 + rank * 1000 + i) for i in range(args.scenes)]
+    if extras:
+        jobs += [("c1", 1001 + i) for i in range(16)]
+    t0 = time.perf_counter()
+    if workers > 1:
+        with mp.get_context("spawn").Pool(workers) as pool:
+            res = pool.map(_scene_job, jobs, chunksize=1)
+    else:
+        res = [_scene_job(j) for j in jobs]
+    c2 = res[: args.scenes]
+    c1 = res[args.scenes :]
+    c3 = None
+    if args.c3_frames >= 8 and not args.profile_region:
+        c3 = synth.sequence_c3(args.c3_frames, seed=3003, workers=workers)
+    return c2, c1, c3, workers, time.perf_counter() - t0
+
+
+def main():
+    args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    extras = world == 1 and not args.no_extras and not args.profile_region
+    c2, c1, c3, gen_workers, gen_s = make_inputs(args, rank, world, extras)
+
+    import numpy as np
+    import torch
+
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("VO_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
     if world > 1:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        # RCCL ("nccl") is the backend of the real runs; VO_BENCH_BACKEND=gloo rehearses the N > 1 path with several ranks on
-        # one GPU (RCCL refuses two ranks on the same device)
-        backend = os.environ.get("VO_BENCH_BACKEND", "nccl")
+        # RCCL ("nccl") is the backend of the real runs; gloo rehearses the N > 1 path with several ranks on one GPU (RCCL
+        # refuses two ranks on the same device) and is chosen by itself when there are fewer GPUs than ranks
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    coll_dev = "cuda" if world > 1 and os.environ.get("VO_BENCH_BACKEND", "nccl") == "nccl" else "cpu"
-    dev = local_rank if torch.cuda.device_count() > local_rank else 0
+    coll_dev = "cuda" if world > 1 and backend == "nccl" else "cpu"
+    dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
 
-    from visual_odometry_amd import synth
+    from visual_odometry_amd import shard, synth
     from visual_odometry_amd._abi import default_params
-    from visual_odometry_amd.frontend import Batch, Context
+    from visual_odometry_amd.frontend import Batch, Context, Sequence
 
-    H, W = 1080, 1920
+    H, W, B = 1080, 1920, args.batch
     prm = default_params()
     prm.roi_x_lo, prm.roi_y_lo, prm.roi_x_hi, prm.roi_y_hi = synth.roi_for(H, W)
     ctx = Context(prm, device=dev)
     if args.matcher == "fp32":
         ctx.debug_set(2, 1)
-    scenes = [synth.scene_c2(2002 + rank * 100 + i) for i in range(args.scenes)]
-    batch = Batch(ctx, args.batch, H, W)
-    for i in range(args.batch):
-        sc = scenes[i % len(scenes)]
-        batch.set_pair(i, sc.img1, sc.img2, sc.K)
-    batch.sync()  # frames are resident in HBM from here on
+    batch = Batch(ctx, B, H, W)
+
+    def fill(k):
+        # step k stages pair (i + k) mod scenes at position i: every step uploads different frames into every slot
+        for i in range(B):
+            img1, img2, K = c2[(i + k) % len(c2)]
+            batch.set_pair(i, img1, img2, K)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    def max_over_ranks(dt):
+        if world > 1:
+            tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            return float(tmax.item())
+        return dt
+
+    def stage_pass(nprof):
+        """per-kernel device time: stage timers on = every kernel alone on the main stream, HIP events around each"""
+        ctx.profile_enable(True)
+        ctx.profile_reset()
+        for _ in range(nprof):
+            batch.run()
+            batch.sync()
+        prof = ctx.profile()
+        ctx.profile_enable(False)
+        return {k: v[0] / nprof for k, v in prof.items()}
+
+    if args.profile_region:
+        fill(0)
         batch.run()
+        batch.sync()
+        stage_ms = stage_pass(max(args.steps, 1))
+        if rank == 0:
+            print(json.dumps({"profile_region": True, "steps": max(args.steps, 1), "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}))
+        batch.close()
+        ctx.close()
+        if world > 1:
+            dist.barrier()
+            dist.destroy_process_group()
+        return
+
+    # ---- headline: PCIe-inclusive steady state ---------------------------------------------------------------------
+    # A step = stage + upload both frames of every pair, run the pipeline on them, have the result records on the host.  The
+    # batch is a two-deep pipeline: while run k executes, the host stages the frames of step k + 1 into the other frame slot.
+    # The warm-up leaves the pipeline primed (frames of the first timed step staged), so the timed region holds exactly
+    # `steps` runs, `steps` stagings and `steps` record read-backs; the upload of the first timed step runs with the GPU
+    # idle (it is inside the region, after the barrier).
+    fill(0)
+    for k in range(args.warmup):
+        batch.run()
+        fill(k + 1)
+        if k > 0:
+            _ = [batch.get(i, age=1) for i in range(B)]
     batch.sync()
     barrier()
     t0 = time.perf_counter()
+    for k in range(args.steps):
+        batch.run()  # upload (copy stream) + kernels of step k
+        fill(args.warmup + k + 1)  # pinned staging of step k + 1, beside step k's kernels
+        if k > 0:
+            _ = [batch.get(i, age=1) for i in range(B)]  # records of step k - 1: on the host since that step finished
+    batch.sync()
+    outs = [batch.get(i) for i in range(B)]
+    barrier()
+    dt = max_over_ranks(time.perf_counter() - t0)
+
+    # result records of this rank's pairs of the last step; their gather is the only collective of the job
+    rec_local = shard.pack_records(outs)
+    rec_all = shard.gather_records(rec_local, B * world, rank, world, device=coll_dev)
+
+    # frames resident in HBM (reported beside `value`): the same batch re-run without new uploads
+    barrier()
+    tr = time.perf_counter()
     for _ in range(args.steps):
         batch.run()
     batch.sync()
     barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt_res = max_over_ranks(time.perf_counter() - tr)
 
-    # result records of this rank's pairs; the gather of these records is the only collective of the job
-    from visual_odometry_amd import shard
-
-    outs = [batch.get(i) for i in range(args.batch)]
-    rec_local = shard.pack_records(outs)
-    rec_all = shard.gather_records(rec_local, args.batch * world, rank, world, device=coll_dev)
-
-    # PCIe-inclusive rate (reported beside `value`, never as `value`): every step uploads both frames of every pair from
-    # host memory and reads the result records back.  Two batches on two contexts (= two HIP streams) alternate, so the
-    # host-side staging and the H2D copies of one step overlap the kernels of the previous one.
-    h2d_steps = 6
-    ctx_b = Context(prm, device=dev)
-    batch_b = Batch(ctx_b, args.batch, H, W)
-    duo = [batch, batch_b]
-
-    def fill(bt):
-        for i in range(args.batch):
-            sc = scenes[i % len(scenes)]
-            bt.set_pair(i, sc.img1, sc.img2, sc.K)
-
-    fill(batch_b)
-    batch_b.run()
-    batch_b.sync()  # warm-up of the second context
-    barrier()
-    th = time.perf_counter()
-    for k in range(h2d_steps):
-        cur = duo[k % 2]
-        fill(cur)
-        cur.run()
-        if k > 0:
-            prev = duo[(k - 1) % 2]
-            prev.sync()
-            _ = [prev.get(i) for i in range(args.batch)]
-    last = duo[(h2d_steps - 1) % 2]
-    last.sync()
-    _ = [last.get(i) for i in range(args.batch)]
-    barrier()
-    pcie_rate = args.batch * h2d_steps * world / (time.perf_counter() - th)
-    # the same two batches, frames resident: the latency-bound kernels of one (RANSAC, sort, pose: ~2 ms of single wavefronts)
-    # run under the VALU-bound kernels of the other.  Reported beside `value` (whose kernels run alone, so that the per-kernel
-    # durations behind `roofline` mean something).
-    for b2 in duo:
-        b2.run()
-    for b2 in duo:
-        b2.sync()
-    barrier()
-    t2 = time.perf_counter()
-    duo_steps = 4
-    for _ in range(duo_steps):
-        for b2 in duo:
-            b2.run()
-    for b2 in duo:
-        b2.sync()
-    barrier()
-    duo_rate = 2 * args.batch * duo_steps * world / (time.perf_counter() - t2)
-    batch_b.close()
-    ctx_b.close()
-
-    # Consecutive-frame mode (reported beside `value`, never as `value`): the reference re-detects prev_img in every loop
-    # iteration, so the headline counts two detections per pair; an offline replay of consecutive frames detects each
-    # frame once (vo_seq_*: batch + 1 frames, pair p = frames p, p + 1), the same matcher / RANSAC work per pair.
-    from visual_odometry_amd.frontend import Sequence
-
-    seq = Sequence(ctx, args.batch + 1, H, W)
-    for f in range(args.batch + 1):
-        sc = scenes[(f // 2) % len(scenes)]
-        seq.set_frame(f, sc.img1 if f % 2 == 0 else sc.img2)  # alternate the two views: every consecutive pair has parallax
-    for p in range(args.batch):
-        seq.set_pair(p, p, p + 1, scenes[0].K)
-    seq.run()
-    seq.sync()
-    barrier()
-    ts = time.perf_counter()
-    seq_steps = 4
-    for _ in range(seq_steps):
-        seq.run()
-    seq.sync()
-    barrier()
-    seq_rate = args.batch * seq_steps * world / (time.perf_counter() - ts)
-    seq.close()
-
-    # per-stage device time of one more pass (HIP events on the library's stream)
-    ctx.profile_enable(True)
-    ctx.profile_reset()
-    nprof = 3
-    for _ in range(nprof):
-        batch.run()
-        batch.sync()  # one run at a time: no geometry-stream overlap inside the per-kernel durations
-    prof = ctx.profile()
-    ctx.profile_enable(False)
+    stage_ms = stage_pass(3)
     import ctypes as C
 
     redo = C.c_int32(-1)  # queries of the last step whose matcher shortlist was not certified (exact scan instead)
     ctx._chk(ctx.lib.vo_debug_fetch(ctx._h, 4, C.byref(redo), C.c_size_t(4)))
 
-    # Latency of the reference's three calls on ONE pair through the synchronous entry points, host buffers in and out - how
-    # the ROS node calls them (reported beside `value`; rank 0 only)
-    single = None
-    if rank == 0:
-        lat = {"opt_DetectFeatures": [], "optRelativePose": [], "triangPoints": []}
-        sc0 = scenes[0]
-        for it in range(13):
-            t0 = time.perf_counter()
-            g = ctx.opt_DetectFeatures(sc0.img1, sc0.img2)
-            t1 = time.perf_counter()
-            _st, R1, tv1, inl1, ok1 = ctx.optRelativePose(g, sc0.K)
-            t2 = time.perf_counter()
-            if ok1:
-                ctx.triangPoints(inl1.Kpoints1, inl1.Kpoints2, R1, tv1, sc0.K)
-            t3 = time.perf_counter()
-            if it >= 3:
-                lat["opt_DetectFeatures"].append(t1 - t0), lat["optRelativePose"].append(t2 - t1), lat["triangPoints"].append(t3 - t2)
-        single = {k + "_ms": round(1e3 * float(np.median(v)), 3) for k, v in lat.items()}
-        single["total_ms"] = round(sum(single.values()), 3)
-        single["note"] = "one 1080p pair, synchronous C-ABI calls with pageable host buffers in and out (median of 10)"
+    # ---- BASELINE configs[2]: the C3 run, frames in blocks over the ranks (replay_sharded) ----------------------------
+    c3_out = None
+    if c3 is not None:
+        from visual_odometry_amd import replay
+        from visual_odometry_amd._abi import default_params as dp
+
+        ctx3 = Context(dp(), device=dev)  # the reference's own ROI (28/20/614/482) is the one for 640 x 505 frames
+        n3 = len(c3.frames)
+        stamps, alt = 0.1 * np.arange(n3), np.full(n3, 7.0)
+        stats = {}
+        replay.replay_sharded(ctx3, c3.frames[: max(8, n3 // 8)], stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev)  # warm-up
+        barrier()
+        t3 = time.perf_counter()
+        recs = replay.replay_sharded(ctx3, c3.frames, stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev, stats=stats)
+        barrier()
+        d3 = max_over_ranks(time.perf_counter() - t3)
+        fails = [r["fail"] for r in recs]
+        c_true = -c3.Rw[-1].T @ c3.tw[-1]
+        c3_out = {"value": round((n3 - 1) / d3, 2), "unit": "frames/s (one loop iteration of the node per frame)", "frames": n3, "size": "640x505",
+                  "K": "config/rapallo_intrinsic.yaml via updateCameraMatrix", "ranks": world, "seconds": round(d3, 4),
+                  "success": fails.count(3), "not_moving": fails.count(1), "fail_recover": fails.count(2), "fail_detection": fails.count(0),
+                  "waves": stats.get("waves"), "gap_pairs": stats.get("gap_pairs"),
+                  "end_position_error_m": round(float(np.linalg.norm(recs[-1]["estimate_pos"] - c_true)), 3),
+                  "path_length_m": round(float(sum(c3.relative(k - 1, k)[2] for k in range(1, n3))), 2),
+                  "note": "includes the per-chunk upload of the frames, result read-back, the gather of pair summaries and the host loop"}
+        ctx3.close()
+
+    extras_out = {}
+    if extras and rank == 0:
+        extras_out = run_extras(np, ctx, prm, c2, c1, dev, args)
 
     if rank == 0:
-        assert rec_all.shape[0] == args.batch * world
+        assert rec_all.shape[0] == B * world
         kp = float(rec_all[:, 1:3].mean())
-        stage_ms = {k: v[0] / nprof for k, v in prof.items()}
-        frames = 2 * args.batch
+        frames = 2 * B
         S = layer_samples(H, W)
         I = 4 * (H + 1) * (W + 1)
         # share of the Hessian samples per octave, and of the keypoints / window samples per descriptor class
         S_oct = [5 * (H >> o) * (W >> o) for o in range(4)]
-        kp1, _ = ctx.detect_describe(scenes[0].img1)
+        kp1, _ = ctx.detect_describe(c2[0][0])
         win = (21 * (kp1["size"].astype(np.float32) * np.float32(1.2) / np.float32(9.0))).astype(np.int64)
         cls_share, cls_samples = {}, {}
         for name, lo, hi in (("describe_w64", 0, 64), ("describe_w128", 64, 128), ("describe_w320", 128, 320), ("describe_w768", 320, 768)):
@@ -243,22 +291,20 @@ def main():
             "hessian_oct1": ("hbm", hess_bytes(S_oct[1])),
             # 2*64*N1*N2 algorithmic flop per pair; the kernel EXECUTES 3.125x that on the bf16 matrix pipe (three bf16 partial
             # products per FP32 product plus the norm step: 25 v_mfma_f32_32x32x16_bf16 per two 32x32 tiles instead of 8)
-            "match_mfma": ("mfma", args.batch * 2 * 64 * float(rec_all[:, 1].mean()) * float(rec_all[:, 2].mean())),
+            "match_mfma": ("mfma", B * 2 * 64 * float(rec_all[:, 1].mean()) * float(rec_all[:, 2].mean())),
         }
         for name, sh in cls_share.items():
             alg[name] = ("hbm", frames * (sh * (H * W + I) + 256 * kp * sh))
 
         # HBM-side traffic per launch: PMC counters cannot be read from inside this process; the figures come from the
-        # committed rocprofv3 --pmc passes of this same command (profiles/) and apply to the default
-        # workload only
+        # committed rocprofv3 --pmc passes of `bench.py --profile-region` (profiles/): default workload only
         traffic = {}
-        tpath = os.path.join(ROOT, "profiles", "r01_r_hbm_traffic.json")  # PMC passes of this command
-        if args.batch == 64 and os.path.exists(tpath):
+        if B == 64 and os.path.exists(TRAFFIC_JSON):
             prefix = {"describe_w64": "k_describe_tiled<64,", "describe_w128": "k_describe_tiled<128,",
                       "describe_w320": "k_describe_tiled<320,", "describe_w768": "k_describe_tiled<768,",
-                      "hessian_oct0_23": "k_hessian_nms_fused<", "hessian_oct1": "k_hessian_nms_lds<", "integral": "k_integral<",
+                      "hessian_oct0_23": "k_hessian_nms_fused<", "hessian_oct1": "k_hessian_nms_lds<", "integral": "k_integral",
                       "match_mfma": "k_match_bf3"}
-            tj = json.load(open(tpath))
+            tj = json.load(open(TRAFFIC_JSON))
             for st, pf in prefix.items():
                 for kname, v in tj.items():
                     if kname.startswith(pf):
@@ -295,38 +341,21 @@ def main():
         roofline = roof(dom)
         # The descriptor and Hessian kernels are bound by VALU issue and the texture addresser's gather rate, not by HBM
         # (PMC evidence under profiles/): their HBM fraction is small by construction.
-        roofline["note"] = "dominant kernel by device time; descriptor/Hessian kernels are VALU-issue / gather bound, see roofline_all and DESIGN.md"
+        roofline["note"] = ("dominant kernel by device time, timed alone on the main stream (the condition `bench.py --profile-region` "
+                            "reproduces under rocprofv3); descriptor/Hessian kernels are VALU-issue / gather bound, see roofline_all and DESIGN.md")
         roofline_all = [roof(k) for k in sorted(alg, key=lambda k: -stage_ms.get(k, 0.0))]
 
         cpu = None
         if not args.no_cpu_baseline and world == 1:  # the CPU port is timed at N = 1 only (rank 0 is the only rank there)
-            import oracle_lib as O
+            cpu = cpu_baseline(np, c2, prm)
 
-            cores = min(len(os.sched_getaffinity(0)), 16)
-            O.set_threads(cores)
-            O.pair(scenes[0].img1, scenes[0].img2, scenes[0].K, prm)  # warm-up
-            tc = time.perf_counter()
-            n_cpu = 0
-            while n_cpu < args.cpu_pairs and (time.perf_counter() - tc) < 30.0:
-                sc = scenes[n_cpu % len(scenes)]
-                O.pair(sc.img1, sc.img2, sc.K, prm)
-                n_cpu += 1
-            cdt = time.perf_counter() - tc
-            O.set_threads(1)
-            t1 = time.perf_counter()
-            O.pair(scenes[0].img1, scenes[0].img2, scenes[0].K, prm)
-            one_thread = 1.0 / (time.perf_counter() - t1)
-            O.set_threads(cores)
-            cpu = {"value": round(n_cpu / cdt, 4), "unit": "frame-pairs/s", "cores": cores, "kind": "port",
-                   "value_1_thread": round(one_thread, 4),
-                   "sample": f"{n_cpu} of the same synthetic 1080p pairs through oracle/libvo_oracle.so (OpenMP, {cores} threads)"}
-
-        pairs = args.batch * args.steps * world
+        pairs = B * args.steps * world
         line = {
             "metric": "frame-pairs/sec (detect+match+E-RANSAC) 1080p/8k kpts",
             "value": round(pairs / dt, 3),
             "unit": "frame-pairs/s",
-            "n_gpus": world,
+            "n_gpus": min(world, max(ndev, 1)) if backend != "nccl" else world,
+            "ranks": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(dt / args.steps * 1e3, 4),
@@ -337,31 +366,239 @@ def main():
                      + ") / f64 (RANSAC, pose, DLT)",
             "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: synthetic 1080p textured frame pairs, SURF ~8k kpts/frame, full "
-                                   "detect x2 / BF match / E-RANSAC / recoverPose / triangulate",
-                       "pairs_per_step_per_gpu": args.batch, "distinct_pairs_per_gpu": len(scenes),
+                                   "detect x2 / BF match / E-RANSAC / recoverPose / triangulate; both frames of every pair uploaded from "
+                                   "host memory every step, result records read back (SURVEY 8d)",
+                       "pairs_per_step_per_gpu": B, "distinct_pairs_per_gpu": len(c2),
                        "mean_keypoints_per_frame": round(kp, 1), "mean_matches": round(float(rec_all[:, 3].mean()), 1),
-                       "mean_inliers": round(float(rec_all[:, 4].mean()), 1),
+                       "mean_inliers": round(float(rec_all[:, 4].mean()), 1), "mean_ransac_iterations": round(float(rec_all[:, 8].mean()), 1),
                        "pairs_with_pose": int(rec_all[:, 7].sum()), "pairs_total": int(len(rec_all)),
-                       "parallelism": f"pairs sharded over {world} GPU(s), no data-path collective"},
-            "pcie_inclusive": {"value": round(pcie_rate, 2), "unit": "frame-pairs/s",
-                               "note": "both frames of every pair uploaded from host memory every step (pinned staging, two alternating batches), result records read back"},
-            "two_batches_in_flight": {"value": round(duo_rate, 2), "unit": "frame-pairs/s",
-                                      "note": "two resident batches on two contexts (two HIP streams) alternating; same work per pair as `value`"},
-            "consecutive_frames": {"value": round(seq_rate, 2), "unit": "frame-pairs/s",
-                                   "note": "sequence batch: batch + 1 frames detected once each, pair p = (frame p, frame p + 1); not the headline workload"},
-            "single_pair_latency": single,
+                       "parallelism": f"pairs sharded over {world} rank(s), one GPU each, no data-path collective; result records all-gathered ({backend})",
+                       "input_generation_s": round(gen_s, 1), "input_generation_workers": gen_workers},
+            "resident": {"value": round(pairs / dt_res, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt_res / args.steps * 1e3, 4),
+                         "note": "same batch re-run with the frames already in HBM (no upload): what `value` would be without PCIe"},
+            "pcie_gap": round(1.0 - (pairs / dt) / (pairs / dt_res), 4),
+            "c3_replay": c3_out,
             "roofline": roofline,
             "roofline_all": roofline_all,
             "cpu_baseline": cpu,
             "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()},
             "match_exact_scans_per_step": redo.value,
         }
+        line.update(extras_out)
         print(json.dumps(line))
     batch.close()
     ctx.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline(np, c2, prm):
+    """The CPU restatement (oracle/, OpenMP over layers / keypoints / query rows like OpenCV's parallel_for_) on the same
+    pairs, on this host: median of 5 repetitions of a bounded sample, all the threads this job may use."""
+    import oracle_lib as O
+
+    avail = len(os.sched_getaffinity(0))
+    threads = max(1, min(avail, int(os.environ.get("OMP_NUM_THREADS", str(avail)))))  # the GPU box caps its jobs' thread pools with OMP_NUM_THREADS
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    O.set_threads(threads)
+    sample = c2[: min(4, len(c2))]
+    O.pair(sample[0][0], sample[0][1], sample[0][2], prm)  # warm-up
+    rates, t_all = [], time.perf_counter()
+    for _ in range(5):
+        tc = time.perf_counter()
+        for img1, img2, K in sample:
+            O.pair(img1, img2, K, prm)
+        rates.append(len(sample) / (time.perf_counter() - tc))
+        if time.perf_counter() - t_all > 25.0 and len(rates) >= 3:
+            break
+    O.set_threads(1)
+    t1 = time.perf_counter()
+    O.pair(sample[0][0], sample[0][1], sample[0][2], prm)
+    one_thread = 1.0 / (time.perf_counter() - t1)
+    O.set_threads(threads)
+    return {"value": round(float(np.median(rates)), 4), "unit": "frame-pairs/s", "cores": threads, "kind": "port",
+            "host_cpus_visible": avail, "cpu_model": model, "value_1_thread": round(one_thread, 4),
+            "repetitions": [round(r, 4) for r in rates],
+            "sample": f"median of {len(rates)} repetitions of {len(sample)} of the same synthetic 1080p pairs through oracle/libvo_oracle.so "
+                      f"(OpenMP, {threads} threads: the thread budget of this job on the host, {avail} CPUs visible)"}
+
+
+def run_extras(np, ctx, prm, c2, c1, dev, args):
+    """Short legs for the other BASELINE configs (N = 1 only), each with its own roofline entry."""
+    import ctypes as C
+
+    from visual_odometry_amd import synth
+    from visual_odometry_amd._abi import default_params
+    from visual_odometry_amd.frontend import Batch, Context, Sequence
+
+    out = {}
+    H, W, B = 1080, 1920, args.batch
+
+    # consecutive-frame mode (reported beside `value`, never as `value`): the reference re-detects prev_img in every loop
+    # iteration, so the headline counts two detections per pair; an offline replay detects each frame once (vo_seq_*)
+    seq = Sequence(ctx, B + 1, H, W)
+    for f in range(B + 1):
+        sc = c2[(f // 2) % len(c2)]
+        seq.set_frame(f, sc[0] if f % 2 == 0 else sc[1])  # alternate the two views: every consecutive pair has parallax
+    for p in range(B):
+        seq.set_pair(p, p, p + 1, c2[0][2])
+    seq.run()
+    seq.sync()
+    ts = time.perf_counter()
+    for _ in range(4):
+        seq.run()
+    seq.sync()
+    out["consecutive_frames"] = {"value": round(B * 4 / (time.perf_counter() - ts), 2), "unit": "frame-pairs/s",
+                                 "note": "sequence batch, frames resident: batch + 1 frames detected once each, pair p = (frame p, frame p + 1); not the headline workload"}
+    seq.close()
+
+    # single-pair latency of the reference's three calls through the synchronous entry points, pageable host buffers
+    lat = {"opt_DetectFeatures": [], "optRelativePose": [], "triangPoints": []}
+    img1, img2, K = c2[0]
+    for it in range(13):
+        t0 = time.perf_counter()
+        g = ctx.opt_DetectFeatures(img1, img2)
+        t1 = time.perf_counter()
+        _st, R1, tv1, inl1, ok1 = ctx.optRelativePose(g, K)
+        t2 = time.perf_counter()
+        if ok1:
+            ctx.triangPoints(inl1.Kpoints1, inl1.Kpoints2, R1, tv1, K)
+        t3 = time.perf_counter()
+        if it >= 3:
+            lat["opt_DetectFeatures"].append(t1 - t0), lat["optRelativePose"].append(t2 - t1), lat["triangPoints"].append(t3 - t2)
+    single = {k + "_ms": round(1e3 * float(np.median(v)), 3) for k, v in lat.items()}
+    single["total_ms"] = round(sum(single.values()), 3)
+    single["note"] = "one 1080p pair, synchronous C-ABI calls with pageable host buffers in and out (median of 10)"
+    out["single_pair_latency"] = single
+
+    # ---- configs[0] (C1): 640 x 480 Parete-like pairs, reference ROI, PCIe-inclusive like the headline
+    ctx1 = Context(default_params(), device=dev)
+    b1 = Batch(ctx1, 64, 480, 640)
+
+    def fill1(k):
+        for i in range(64):
+            a, b, K1 = c1[(i + k) % len(c1)]
+            b1.set_pair(i, a, b, K1)
+
+    fill1(0)
+    for k in range(2):
+        b1.run()
+        fill1(k + 1)
+    b1.sync()
+    t0 = time.perf_counter()
+    n1 = 10
+    for k in range(n1):
+        b1.run()
+        fill1(3 + k)
+        if k > 0:
+            _ = [b1.get(i, age=1) for i in range(64)]
+    b1.sync()
+    d1 = time.perf_counter() - t0
+    o1 = [b1.get(i) for i in range(64)]
+    S1 = layer_samples(480, 640)
+    kp1 = float(np.mean([o.n_kp1 for o in o1]))
+    alg1 = 2 * (2 * 480 * 640 + 3 * 4 * 481 * 641 + 12 * S1 + 284 * kp1)  # SURVEY 8d "detect total per frame" x 2 frames
+    out["c1_640x480"] = {"value": round(64 * n1 / d1, 1), "unit": "frame-pairs/s", "ms_per_step": round(1e3 * d1 / n1, 3), "pairs_per_step": 64,
+                         "distinct_pairs": len(c1), "mean_keypoints_per_frame": round(kp1, 1), "mean_matches": round(float(np.mean([o.n_match for o in o1])), 1),
+                         "pairs_with_pose": int(sum(o.success for o in o1)),
+                         "roofline": {"bound": "hbm", "achieved": round(alg1 * 64 * n1 / d1 / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                      "frac": round(alg1 * 64 * n1 / d1 / 1e9 / HBM_PEAK_GBS, 5),
+                                      "note": "whole pipeline: SURVEY 8d algorithmic detect bytes per pair x pairs/s"},
+                         "note": "BASELINE configs[0]: Parete-like 640x480 pairs, camera_intrinsic.yaml K, reference ROI; frames uploaded every step"}
+    b1.close()
+    ctx1.close()
+
+    # ---- configs[3] (C4): 32k x 32k descriptor matcher, both matrix formulations (kernel time from the stage timer)
+    prm4 = default_params()
+    c4 = {}
+    da, db = synth.surf_like_descriptors(32768, 4004), synth.surf_like_descriptors(32768, 4005)
+    for name, key in (("bf16x3", 0), ("fp32", 1)):
+        ctx4 = Context(prm4, device=dev)
+        ctx4.debug_set(2, key)
+        ctx4.match_knn2(da, db)  # warm-up (allocations)
+        ctx4.profile_enable(True)
+        ctx4.profile_reset()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            idx, dist_ = ctx4.match_knn2(da, db)
+        wall = (time.perf_counter() - t0) / reps
+        pf = ctx4.profile()
+        ctx4.profile_enable(False)
+        ms = pf["match_mfma"][0] / reps
+        ms_all = (pf["match_prep"][0] + pf["match_mfma"][0] + pf["match_select"][0]) / reps
+        flop = 2.0 * 64 * 32768 * 32768
+        if name == "fp32":
+            ach, peak = (33.0 / 32.0) * flop / (ms * 1e-3) / 1e12, MFMA_F32_PEAK_TFLOPS
+        else:
+            ach, peak = MFMA_EXEC_FACTOR * flop / (ms * 1e-3) / 1e12, MFMA_BF16_PEAK_TFLOPS
+        c4[name] = {"mfma_kernel_ms": round(ms, 4), "matcher_device_ms": round(ms_all, 4), "call_wall_ms": round(1e3 * wall, 3),
+                    "algorithmic_tflops": round(flop / (ms * 1e-3) / 1e12, 2),
+                    "roofline": {"bound": "mfma", "achieved": round(ach, 2), "peak": peak, "unit": "TFLOP/s", "frac": round(ach / peak, 4),
+                                 "note": "executed matrix flop of the shortlist kernel against the dense peak of its instruction"}}
+        if name == "fp32":
+            c4["identical_results"] = bool(np.array_equal(idx, c4.pop("_idx")) and np.array_equal(dist_, c4.pop("_dist")))
+        else:
+            c4["_idx"], c4["_dist"] = idx, dist_
+        ctx4.close()
+    c4["note"] = "BASELINE configs[3]: 32768 x 32768 SURF-like descriptors (137.4 GFLOP algorithmic), exact 2-NN; call_wall includes the 16 MB upload and the result download"
+    out["c4_matcher_32k"] = c4
+
+    # ---- configs[4] (C5): RANSAC stress (8192 matches, 50 % outliers, 4096 hypotheses, adaptive stop off) + 100k-point DLT
+    K5 = synth.K_1080P
+    p1, p2, R5, t5, is_in = synth.correspondences(8192, K5, 5005, inlier_frac=0.5, noise_px=0.5)
+    ctx.essential_ransac(p1, p2, K5, prob=1.0, max_iters=4096)  # warm-up; prob = 1 keeps niters at max_iters (RANSACUpdateNumIters)
+    ctx.profile_enable(True)
+    ctx.profile_reset()
+    reps = 3
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        st, E5, mask5, ninl5, iters5 = ctx.essential_ransac(p1, p2, K5, prob=1.0, max_iters=4096)
+    wall5 = (time.perf_counter() - t0) / reps
+    pf = ctx.profile()
+    ms5 = (pf["ransac_sample"][0] + pf["ransac_solve_score"][0] + pf["ransac_select"][0]) / reps
+    ms5_solve = pf["ransac_solve_score"][0] / reps
+    nm = np.zeros(4096, np.int32)
+    ctx._chk(ctx.lib.vo_debug_fetch(ctx._h, 1, nm.ctypes.data_as(C.c_void_p), C.c_size_t(nm.nbytes)))
+    models = int(nm.sum())
+    flop5 = 35.0 * 8192 * models + 25e3 * 4096  # Sampson scoring of every model on every match + the solver (SURVEY 8d)
+    # triangulation: 100 000 correspondences under the true pose
+    q1, q2, R6, t6, _ = synth.correspondences(100000, K5, 5006, inlier_frac=1.0, noise_px=0.3)
+    P0 = K5 @ np.hstack([np.eye(3), np.zeros((3, 1))])
+    P1 = K5 @ np.hstack([R6, t6[:, None]])
+    ctx.triangulate(P0, P1, q1, q2)
+    ctx.profile_reset()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        X4 = ctx.triangulate(P0, P1, q1, q2)
+    wall6 = (time.perf_counter() - t0) / reps
+    ms6 = ctx.profile()["triangulate"][0] / reps
+    ctx.profile_enable(False)
+    X3 = X4[:3] / X4[3]
+    Xt = (np.linalg.inv(K5) @ np.vstack([q1.T.astype(np.float64), np.ones(len(q1))]))
+    out["c5_ransac_triang"] = {
+        "ransac": {"hypotheses": 4096, "matches": 8192, "iterations_run": int(iters5), "models_scored": models, "inliers": int(ninl5),
+                   "true_inlier_fraction": round(float(is_in.mean()), 3), "device_ms": round(ms5, 3), "solve_score_ms": round(ms5_solve, 3),
+                   "call_wall_ms": round(1e3 * wall5, 3), "hypotheses_per_s": round(4096 / (ms5 * 1e-3), 0),
+                   "roofline": {"bound": "fp64 valu", "achieved": round(flop5 / (ms5_solve * 1e-3) / 1e9, 1), "peak": FP64_VALU_PEAK_TFLOPS * 1e3,
+                                "unit": "GFLOP/s", "frac": round(flop5 / (ms5_solve * 1e-3) / 1e12 / FP64_VALU_PEAK_TFLOPS, 5),
+                                "note": "35 flop per (model, match) Sampson evaluation + 25 kflop per five-point solve, over the solve+score kernels"}},
+        "triangulation": {"points": 100000, "kernel_ms": round(ms6, 4), "call_wall_ms": round(1e3 * wall6, 3),
+                          "roofline": {"bound": "hbm", "achieved": round(32.0 * 100000 / (ms6 * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                       "frac": round(32.0 * 100000 / (ms6 * 1e-3) / 1e9 / HBM_PEAK_GBS, 6),
+                                       "note": "32 algorithmic bytes per point (2 x float2 in, float4 out); the kernel is ~1.5 kflop of fp64 Jacobi per point and one launch: latency bound"},
+                          "median_depth_m": round(float(np.median(X3[2])), 3)},
+        "note": "BASELINE configs[4]: 50 % outliers, 4096 hypotheses per pair with the adaptive stop off (prob = 1), 100k triangulated points"}
+    del Xt
+    return out
 
 
 if __name__ == "__main__":

@@ -399,3 +399,62 @@ def test_two_seeds_on_one_device_do_not_share_a_sample_stream():
     again = ca.essential_ransac(p1, p2, synth.K_PARETE, seed=2**64 - 1)
     assert again[4] == ref_a[4] and np.array_equal(again[2], ref_a[2])
     ba.close(), bb.close(), ca.close(), cb.close()
+
+
+def test_c3_sequence_through_the_sharded_replay(ctx):
+    """BASELINE configs[2] on the GPU: a rapallo-like 640 x 505 run (K from config/rapallo_intrinsic.yaml through
+    updateCameraMatrix, 18 stationary frames) through replay_sharded - frame block, pair summaries, host loop, gap-pair
+    wave - against the on-demand replay (identical records), the CPU oracle on sampled pairs, and the ground truth."""
+    from visual_odometry_amd import chain, replay
+
+    n = 72
+    sc = synth.sequence_c3(n, seed=3003, stationary=((20, 10), (50, 8)))
+    assert sc.frames[0].shape == (505, 640) and abs(sc.K[0, 0] - 2305.660253962050 * 640 / 2560) < 1e-9
+    stamps = 10.0 + 0.1 * np.arange(n)
+    alt = np.full(n, 7.0)
+    stats = {}
+    recs = replay.replay_sharded(ctx, sc.frames, stamps, alt, sc.K, np.eye(3), np.zeros(3), 0, 1, chunk=32, stats=stats)
+    base = replay.replay(ctx, sc.frames, stamps, alt, sc.K, np.eye(3), np.zeros(3), chunk=24)
+    assert len(recs) == len(base) == n - 1
+    for a, b in zip(recs, base):
+        assert (a["frame"], a["prev"], a["n_matches"], a["fail"]) == (b["frame"], b["prev"], b["n_matches"], b["fail"])
+        for key in ("R", "t", "SF", "estimate_pos", "estimate_rpy", "twist_linear", "twist_angular", "world_pointsW"):
+            assert (key in a) == (key in b)
+            if key in a:
+                assert np.array_equal(np.asarray(a[key]), np.asarray(b[key])), (a["frame"], key)
+    fails = [r["fail"] for r in recs]
+    still = {r["frame"] for r in recs if r["fail"] == chain.NOT_MOVING}
+    # the 18 stationary frames, plus the frames of a tight turn of the path (37 -> 38, 39: under 20 px against frame 37)
+    assert set(range(20, 30)) | set(range(50, 58)) <= still and len(still) <= 22, sorted(still)
+    assert stats["waves"] >= 2 and stats["gap_pairs"] >= 2
+    # ~30 px of sideways motion over a seabed with +-17 % of relief is a weak geometry: some pairs fail the cheirality gate
+    # (FAIL_RECOVER, the node then keeps the previous R, t) - on the GPU exactly where the loop's branch was taken
+    assert all(f in (chain.SUCCESS, chain.NOT_MOVING, chain.FAIL_RECOVER) for f in fails), fails
+    moving = [r for r in recs if r["fail"] != chain.NOT_MOVING]
+    assert sum(r["fail"] == chain.SUCCESS for r in moving) >= 0.6 * len(moving)
+    # after a stationary stretch the pair is (last moving frame, first frame that moved again)
+    assert [r["prev"] for r in recs if r["frame"] in (30, 58)] == [19, 49]
+    # sampled pairs against the CPU oracle: detect / match exactly; same verdict and pose within the north star's 0.1 degrees
+    # wherever both sides found the same consensus set
+    sample = [recs[i] for i in (0, 1, 5, 12, 29, 31, 40, 48, 57, 60, 66, 70)]
+    close = 0
+    for r in sample:
+        j, k = r["prev"], r["frame"]
+        ref = O.pair(sc.frames[j], sc.frames[k], sc.K)
+        assert r["n_matches"] == ref.n_match, (j, k)
+        if r["fail"] == chain.NOT_MOVING:
+            continue
+        assert (r["fail"] == chain.SUCCESS) == bool(ref.success), (j, k, r["fail"], ref.n_inl, ref.n_good)
+        if not ref.success:
+            continue
+        if r["n_inliers"] == ref.n_inl:
+            close += 1
+            assert _angle(r["R"], np.array(ref.R).reshape(3, 3)) < 0.1, (j, k)
+            assert np.degrees(np.arccos(np.clip(r["t"] @ np.array(ref.t), -1, 1))) < 0.5, (j, k)
+        Rgt, tgt, bl = sc.relative(j, k)
+        assert _angle(r["R"], Rgt) < 3.0 and np.degrees(np.arccos(np.clip(r["t"] @ tgt, -1, 1))) < 30.0, (j, k)  # weak geometry
+        assert 0.5 * bl < r["SF"] < 2.0 * bl
+    assert close >= 4, close
+    # the chain ends near the true camera position (scale from the altitude / mean depth: a few per cent per step)
+    c_true = -sc.Rw[-1].T @ sc.tw[-1]
+    assert np.linalg.norm(recs[-1]["estimate_pos"] - c_true) < 0.5 * np.linalg.norm(c_true) + 1.0

@@ -946,18 +946,19 @@ int vo_batch_frame_slot(vo_batch* b, int frame, uint8_t** d_dst) {
 }
 
 static int stage_frame(vo_batch* b, int frame, const uint8_t* img, size_t step) {
-    // the caller's buffer may be pageable and may be reused as soon as this returns: the frame goes through the batch's
-    // pinned staging copy; the H2D transfer itself is asynchronous on the batch's COPY stream, into the frame slot the
-    // latest run does not read, so it runs beside that run's kernels
+    // the caller's buffer may be pageable and may be reused as soon as this returns: the frame goes into the batch's pinned
+    // staging copy of the frame slot the latest run does not read.  The H2D transfers are issued by vo_batch_run, one per
+    // contiguous range of staged frames, on the batch's COPY stream (128 separate 2 MB transfers beside a run's kernels cost
+    // the kernels 2.4 ms per step; one 265 MB transfer costs them nothing - tools/pcie_probe*.py)
     uint8_t* d_dst = nullptr;
     VO_TRY(vo_batch_frame_slot(b, frame, &d_dst));
+    b->staged[frame] = 2;  // 2 = the frame is in the pinned staging memory and still has to be uploaded
     const size_t fbytes = (size_t)b->rows * b->cols;
     uint8_t* dst = b->h_stage[b->fill_slot] + (size_t)frame * fbytes;
     if (step == (size_t)b->cols)
         std::memcpy(dst, img, fbytes);
     else
         for (int r = 0; r < b->rows; r++) std::memcpy(dst + (size_t)r * b->cols, img + (size_t)r * step, b->cols);
-    VO_HIP(hipMemcpyAsync(d_dst, dst, fbytes, hipMemcpyHostToDevice, b->stream_copy));
     return VO_OK;
 }
 
@@ -1038,11 +1039,18 @@ extern "C" int vo_batch_run(vo_batch* b) {
     std::memcpy(rh.frames, b->h_frames.data(), b->h_frames.size() * sizeof(int2));
     if (b->n_staged > 0) {  // frames were staged since the latest run: this run reads the other slot
         const int s = b->fill_slot;
-        if (b->cur_slot >= 0 && b->n_staged < b->n_frames)  // frames that were not replaced carry over
-            for (int f = 0; f < b->n_frames; f++)
-                if (!b->staged[f])
-                    VO_HIP(hipMemcpyAsync(b->d_img[s] + (size_t)f * b->fs.img_stride(), b->d_img[b->cur_slot] + (size_t)f * b->fs.img_stride(),
-                                          b->fs.img_stride(), hipMemcpyDeviceToDevice, b->stream_copy));
+        const size_t fst = b->fs.img_stride();
+        for (int f = 0; f < b->n_frames;) {  // one transfer per run of frames with the same origin
+            const uint8_t kind = b->staged[f];
+            int e = f + 1;
+            while (e < b->n_frames && b->staged[e] == kind) e++;
+            const size_t off = (size_t)f * fst, bytes = (size_t)(e - f) * fst;
+            if (kind == 2)  // staged by vo_batch_set_pair / vo_seq_set_frame: host -> device
+                VO_HIP(hipMemcpyAsync(b->d_img[s] + off, b->h_stage[s] + off, bytes, hipMemcpyHostToDevice, b->stream_copy));
+            else if (kind == 0 && b->cur_slot >= 0)  // not replaced: carries over from the slot the latest run read
+                VO_HIP(hipMemcpyAsync(b->d_img[s] + off, b->d_img[b->cur_slot] + off, bytes, hipMemcpyDeviceToDevice, b->stream_copy));
+            f = e;  // kind 1: written on the device by vo_prep_to_batch (main stream), nothing to copy
+        }
         VO_HIP(hipEventRecord(b->ev_h2d[s], b->stream_copy));
         b->h2d_pending[s] = true;
         VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_h2d[s], 0));

@@ -246,3 +246,122 @@ def bgr_frame(rows: int, cols: int, seed: int, contrast: float = 0.5) -> np.ndar
         ch = offs + contrast * gain * (base + fine + _value_noise(rng, rows, cols, 9, 12.0)) + rng.normal(0.0, 2.0, (rows, cols))
         out[..., c] = np.clip(np.rint(ch), 0, 255).astype(np.uint8)
     return out
+
+
+# ---- C3: Rapallo-like survey run -------------------------------------------------------------------------
+def k_rapallo_640() -> np.ndarray:
+    """K of the node on the rapallo camera: config/rapallo_intrinsic.yaml through updateCameraMatrix for the 2560 x 2056
+    frames of that camera and its desired_size 640 x 505 (camera_utility.hpp:138-145)."""
+    import os
+
+    from .config import load_camera_config
+
+    cfg = load_camera_config(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "config", "rapallo_intrinsic.yaml"))
+    return cfg.K_for(2560, 2056)
+
+
+_C3 = {}
+
+
+def _c3_init(world):
+    _C3.update(world)
+
+
+def _c3_frame(k):
+    """frame k of the run held in _C3 (set by _c3_init in this process): blobs in view rendered over fresh seeded noise"""
+    g = _C3
+    h, w, K = g["h"], g["w"], g["K"]
+    Rk, tk = g["Rw"][k], g["tw"][k]
+    Xk = Rk @ g["X0"] + tk[:, None]
+    uv = (K @ Xk)[:2] / Xk[2]
+    sig = g["sa"] * g["za"] / Xk[2]
+    m = 4.0 * sig + 2.0
+    vis = (Xk[2] > 0.5) & (uv[0] > -m) & (uv[0] < w + m) & (uv[1] > -m) & (uv[1] < h + m)
+    noise = _value_noise(np.random.default_rng([g["seed"], k]), h, w, 6, g["noise_amp"])
+    return _render(h, w, uv[:, vis].T, sig[vis], g["aa"][vis], noise)
+
+
+def sequence_c3(n_frames: int = 512, seed: int = 3003, h: int = 505, w: int = 640, K: np.ndarray | None = None, step_m: float = 0.36,
+                stationary=((60, 10), (250, 6), (400, 9)), depth: float = 7.0, relief: float = 1.2, density: float = 11.0,
+                workers: int = 1) -> SequenceScene:
+    """BASELINE configs[2] stand-in (the reference's rapallo bags are not in its repository): a down-looking camera over a
+    blob seabed (plane at `depth` m with +-`relief` m of relief), moving `step_m` per frame along a cubic spline through
+    seeded waypoints with slowly varying roll / pitch / yaw - about 30 px of image motion per frame at the rapallo K -
+    and standing still for the `stationary` stretches ((first frame, length), ...: their pairs are NOT_MOVING, >= 16 frames
+    by default).  Frames are independent given the world, so `workers` > 1 renders them in a process pool (spawned: call
+    before anything initialises the GPU)."""
+    from scipy.interpolate import CubicSpline
+
+    K = k_rapallo_640() if K is None else np.asarray(K, np.float64)
+    rng = np.random.default_rng(seed)
+    still = np.zeros(n_frames, bool)
+    for f0, ln in stationary:
+        still[f0 : min(f0 + ln, n_frames)] = True
+    still[0] = False
+    n_move = int((~still).sum())
+    length = step_m * n_move
+    # waypoints: a lawnmower-like walk inside a box, so that the world stays small while the path is long
+    box = np.array([max(30.0, length / 6.0), max(16.0, length / 12.0)])
+    way, total = [np.zeros(2)], 0.0
+    while total < 1.15 * length + 20.0 or len(way) < 6:
+        for _ in range(50):
+            a = rng.uniform(0, 2 * np.pi)
+            cand = way[-1] + rng.uniform(9.0, 16.0) * np.array([np.cos(a), np.sin(a)])
+            if np.all(np.abs(cand) < box / 2):
+                break
+        cand = np.clip(cand, -box / 2, box / 2)
+        total += float(np.linalg.norm(cand - way[-1]))
+        way.append(cand)
+    way = np.array(way)
+    chord = np.r_[0.0, np.cumsum(np.linalg.norm(np.diff(way, axis=0), axis=1))]
+    spl = CubicSpline(chord, way)
+    dense = spl(np.linspace(0, chord[-1], 20000))
+    arc = np.r_[0.0, np.cumsum(np.linalg.norm(np.diff(dense, axis=0), axis=1))]
+    if arc[-1] < length:
+        raise ValueError("path shorter than the run: more waypoints needed")
+    s_of = np.interp(step_m * np.arange(n_move), arc, np.arange(len(arc)))
+    xy_move = np.stack([np.interp(s_of, np.arange(len(arc)), dense[:, 0]), np.interp(s_of, np.arange(len(arc)), dense[:, 1])], 1)
+    # world: features over the band the views sweep
+    half = np.array([0.5 * w / K[0, 0], 0.5 * h / K[1, 1]]) * (depth + relief) * 1.5
+    lo, hi = dense.min(0) - half, dense.max(0) + half
+    n_feat = int(density * np.prod(hi - lo))
+    fx_, fy_ = rng.uniform(lo[0], hi[0], n_feat), rng.uniform(lo[1], hi[1], n_feat)
+    fz = depth + _value_noise(rng, 64, 64, 8, relief)[rng.integers(0, 64, n_feat), rng.integers(0, 64, n_feat)] + rng.uniform(-0.2, 0.2, n_feat)
+    s_m = np.exp(rng.uniform(np.log(0.02), np.log(0.075), n_feat))  # spot radius in metres
+    amp = rng.uniform(30.0, 90.0, n_feat) * rng.choice([-1.0, 1.0], n_feat)
+    ns = 3
+    phi = rng.uniform(0, 2 * np.pi, (ns, n_feat))
+    rad = rng.uniform(1.2, 2.8, (ns, n_feat)) * s_m
+    sfac = rng.uniform(0.5, 0.9, (ns, n_feat))
+    afac = rng.uniform(0.35, 0.9, (ns, n_feat)) * rng.choice([-1.0, 1.0], (ns, n_feat))
+    X0 = np.stack([np.concatenate([fx_] + [fx_ + rad[i] * np.cos(phi[i]) for i in range(ns)]),
+                   np.concatenate([fy_] + [fy_ + rad[i] * np.sin(phi[i]) for i in range(ns)]), np.tile(fz, ns + 1)])
+    # spot size in pixels at frame k = f * radius / Z: stored as sigma at unit focal length, za = f so that sa * za / Z works
+    sa = np.concatenate([s_m] + [sfac[i] * s_m for i in range(ns)])
+    aa = np.concatenate([amp] + [afac[i] * amp for i in range(ns)])
+    za = np.full(sa.shape, 0.5 * (K[0, 0] + K[1, 1]))
+    # poses: camera k at (x, y, 0) of the world frame with a slowly varying attitude; a stationary frame repeats the pose
+    Rw, tw, mv = [], [], 0
+    for k in range(n_frames):
+        if not still[k]:
+            i = mv
+            mv += 1
+        c = np.array([xy_move[i, 0], xy_move[i, 1], 0.0])
+        rv = np.array([1.5 * np.sin(0.021 * i + 0.3), 1.5 * np.cos(0.017 * i), 25.0 * np.sin(0.006 * i + 1.0)])
+        Rk = rodrigues(np.deg2rad(rv)).T
+        Rw.append(Rk)
+        tw.append(-Rk @ c)
+    world = {"h": h, "w": w, "K": K, "Rw": Rw, "tw": tw, "X0": X0, "sa": sa, "aa": aa, "za": za, "seed": seed, "noise_amp": 2.0}
+    if workers > 1:
+        import multiprocessing as mp
+
+        with mp.get_context("spawn").Pool(workers, initializer=_c3_init, initargs=(world,)) as pool:
+            frames = pool.map(_c3_frame, range(n_frames), chunksize=max(1, n_frames // (4 * workers)))
+    else:
+        _c3_init(world)
+        frames = [_c3_frame(k) for k in range(n_frames)]
+    # ground truth relative to camera 0 (SequenceScene convention: X_k = Rw[k] X_0 + tw[k] with frame 0 the reference)
+    R0, t0 = Rw[0], tw[0]
+    Rrel = [Rk @ R0.T for Rk in Rw]
+    trel = [tk - Rr @ t0 for tk, Rr in zip(tw, Rrel)]
+    return SequenceScene(frames, K.copy(), Rrel, trel)
