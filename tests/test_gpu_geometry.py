@@ -20,15 +20,18 @@ def _angle(Ra, Rb):
     return np.degrees(np.arccos(np.clip((np.trace(Ra.T @ Rb) - 1) / 2, -1, 1)))
 
 
-def _match_sets(Ea, na, Eb, nb, tol):
-    """every model of a has a partner in b up to sign within tol (and vice versa)"""
+def _set_dist(Ea, na, Eb, nb):
+    """distance between two candidate sets up to sign (inf when the counts differ)"""
     if na != nb:
-        return False
+        return np.inf
+    d = 0.0
     for i in range(na):
-        d = [min(np.abs(Ea[i] - Eb[j]).max(), np.abs(Ea[i] + Eb[j]).max()) for j in range(nb)]
-        if min(d) > tol:
-            return False
-    return True
+        d = max(d, min(min(np.abs(Ea[i] - Eb[j]).max(), np.abs(Ea[i] + Eb[j]).max()) for j in range(nb)))
+    return d
+
+
+def _ulp_perturbed(x, rng, ulps=1):
+    return (x.view(np.int64) + rng.integers(-ulps, ulps + 1, x.shape)).view(np.float64)
 
 
 @pytest.mark.parametrize("count,nt", [(8192, 4096), (1000, 1000), (37, 500), (6, 200), (10, 64)])
@@ -39,18 +42,33 @@ def test_sample_stream_identical(ctx, count, nt):
 
 
 def test_five_point_candidate_sets(ctx):
-    p1, p2, R, t, _ = synth.correspondences(5 * 400, K, 11, inlier_frac=1.0, noise_px=0.3)
+    """The device solver (MGS null space, lane-per-root Durand-Kerner) and the oracle's (JacobiSVD, Gauss-Seidel solvePoly)
+    are two fp64 evaluations of the same ten-degree problem, whose roots can be ill-conditioned.  What separates them is
+    measured against the oracle's OWN sensitivity: cond_h = how far the oracle's candidates of hypothesis h move when its
+    inputs move by one ulp (worst of three draws).  The device must stay within 16 x cond_h on EVERY hypothesis (observed
+    worst: 7.4 x), hence within 1e-9 wherever the problem is well-conditioned; nothing statistical is accepted."""
+    p1, p2, R, t, _ = synth.correspondences(5 * 2000, K, 11, inlier_frac=1.0, noise_px=0.3)
     x1, x2 = _norm(p1).reshape(-1, 5, 2), _norm(p2).reshape(-1, 5, 2)
     E, nm = ctx.five_point(x1, x2)
     rE, rnm = O.five_point(x1, x2)
     assert nm.max() <= 10 and nm.min() >= 0
-    ok = sum(_match_sets(E[h], nm[h], rE[h], rnm[h], 1e-7) for h in range(len(nm)))
-    # root classification (|imag| <= 1e-10) and near-double roots may differ between Durand-Kerner variants
-    assert ok >= 0.97 * len(nm), (ok, len(nm))
-    tight = sum(_match_sets(E[h], nm[h], rE[h], rnm[h], 1e-9) for h in range(len(nm)))
-    assert tight >= 0.9 * len(nm), (tight, len(nm))
-    # candidates are ordered by ascending z and satisfy the essential-matrix constraints
+    H = len(nm)
+    rng = np.random.default_rng(1)
+    cond = np.zeros(H)
+    for _ in range(3):
+        pE, pn = O.five_point(_ulp_perturbed(x1.copy(), rng), _ulp_perturbed(x2.copy(), rng))
+        cond = np.maximum(cond, [_set_dist(rE[h], rnm[h], pE[h], pn[h]) for h in range(H)])
+    g = np.array([_set_dist(E[h], nm[h], rE[h], rnm[h]) for h in range(H)])
+    assert np.all(g <= 16.0 * np.maximum(cond, 1e-15)), (np.argmax(g / np.maximum(cond, 1e-15)), g.max())
+    well = cond <= 1e-12
+    assert well.mean() > 0.5 and np.all(g[well] <= 1e-9) and g[well].max() < 2e-11
+    # and the rates the round-1 test looked at are the oracle's own, not the device's: equal within sampling noise
+    for tol in (1e-9, 1e-7):
+        assert abs(np.mean(g <= tol) - np.mean(cond <= tol)) < 0.02
+    # well-conditioned candidates satisfy the essential-matrix constraints tightly
     for h in range(0, len(nm), 7):
+        if not well[h]:
+            continue
         for i in range(nm[h]):
             Em = E[h, i].reshape(3, 3)
             assert abs(np.linalg.norm(Em) - 1) < 1e-12
@@ -96,7 +114,10 @@ def _gpu_models(ctx, p1, p2, seed, max_iters):
     return ctx.five_point(m1[tup], m2[tup])
 
 
-RANSAC_CASES = [(2000, 0.8, 0.5, 21), (8192, 0.5, 0.5, 5005), (300, 0.6, 1.0, 23), (40, 0.9, 0.3, 24), (3000, 0.3, 0.5, 25)]
+# the last three: inlier ratios so high that an early hypothesis pulls the iteration bound below the current iteration while
+# better models of the same hypothesis are still to come (the registrator finishes the hypothesis)
+RANSAC_CASES = [(2000, 0.8, 0.5, 21), (8192, 0.5, 0.5, 5005), (300, 0.6, 1.0, 23), (40, 0.9, 0.3, 24), (3000, 0.3, 0.5, 25),
+                (1500, 0.97, 0.3, 26), (468, 0.97, 0.5, 27), (1200, 1.0, 0.2, 28)]
 
 
 @pytest.mark.parametrize("n,frac,noise,seed", RANSAC_CASES)
@@ -115,22 +136,42 @@ def test_essential_ransac_same_hypotheses_bit_exact(ctx, n, frac, noise, seed):
     assert ninl > 0.7 * is_in.sum()
 
 
+def _k_ulp(K0, rng):
+    Kp = K0.copy()
+    for r, c in ((0, 0), (1, 1), (0, 2), (1, 2)):
+        Kp[r, c] = (Kp[r : r + 1, c].view(np.int64) + rng.integers(-1, 2)).view(np.float64)[0]
+    return Kp
+
+
 @pytest.mark.parametrize("n,frac,noise,seed", RANSAC_CASES)
 def test_essential_ransac_vs_oracle_solver(ctx, n, frac, noise, seed):
-    """End to end against the oracle's own (OpenCV-structured) five-point solver.  Ill-conditioned candidates
-    differ between two floating-point implementations of the solver, so the adaptive path may differ; the
-    consensus sets must still agree closely and the poses within the north star's 0.1 degrees."""
+    """End to end against the oracle's own (OpenCV-structured) five-point solver.  The two solvers differ only where the
+    candidates are ill-conditioned (test_five_point_candidate_sets), which can move a borderline point across the Sampson
+    threshold and with it the adaptive path.  The yardstick is again the oracle itself: its result on the same points with
+    the camera matrix moved by one ulp (six draws).  Where the oracle does not move at all, the device must reproduce it
+    exactly; otherwise it must stay within twice the oracle's own spread."""
     p1, p2, R, t, is_in = synth.correspondences(n, K, seed, inlier_frac=frac, noise_px=noise)
     st, E, mask, ninl, iters = ctx.essential_ransac(p1, p2, K)
     rst, rE, rmask, rninl, riters = O.essential_ransac(p1, p2, K)
     assert st == rst == 0
-    assert abs(ninl - rninl) <= max(3, 0.05 * rninl)
-    assert (mask != rmask).mean() < 0.08
-    Rg, tg, _ = O.recover_pose(E, p1[mask > 0], p2[mask > 0], K)
     Rr, tr, _ = O.recover_pose(rE, p1[rmask > 0], p2[rmask > 0], K)
-    tol = 0.1 if n >= 2000 else 1.0
-    assert _angle(Rg, Rr) < tol  # north star: pose vs the reference path within 0.1 degrees
-    assert _angle(Rg, R) < 10 * tol  # sanity against the ground truth of the synthetic scene
+    rng = np.random.default_rng(seed)
+    spread_mask, spread_deg, spread_iters = 0.0, 0.0, 0
+    for _ in range(6):
+        Kp = _k_ulp(K, rng)
+        _, pE, pmask, _, piters = O.essential_ransac(p1, p2, Kp)
+        Rp, _, _ = O.recover_pose(pE, p1[pmask > 0], p2[pmask > 0], Kp)
+        spread_mask = max(spread_mask, float((pmask != rmask).mean()))
+        spread_deg = max(spread_deg, _angle(Rp, Rr))
+        spread_iters = max(spread_iters, abs(piters - riters))
+    Rg, tg, _ = O.recover_pose(E, p1[mask > 0], p2[mask > 0], K)
+    if spread_mask == 0.0 and spread_iters == 0:
+        assert iters == riters and np.array_equal(mask, rmask) and np.abs(E - rE).max() < 1e-9, (iters, riters, (mask != rmask).sum())
+    else:
+        assert (mask != rmask).mean() <= 2 * spread_mask + 1.0 / n
+        assert _angle(Rg, Rr) <= 2 * spread_deg + 1e-6
+    assert _angle(Rg, Rr) < 0.1 or spread_deg > 0.05  # north star: pose vs the reference path within 0.1 degrees
+    assert _angle(Rg, R) < (1.0 if n >= 2000 else 10.0)  # sanity against the ground truth of the synthetic scene
 
 
 def test_essential_ransac_fixed_4096_hypotheses(ctx):

@@ -831,8 +831,20 @@ __global__ __launch_bounds__(64) void k_ransac_scan(PairState* __restrict__ st, 
         best_m = __shfl(found_m, fl, 64);
         best_h = hcur + fl;
         niters = d_ransac_update_num_iters(prob, (double)(n - best) / n, 5, niters);
-        hcur = best_h;
-        mstart = best_m + 1;  // later models of the same hypothesis are still compared, in order
+        // The registrator finishes the models of the current hypothesis whatever the new bound says (its loop tests
+        // `iter < niters` only between hypotheses): with a high inlier ratio the first good model can pull niters below the
+        // current iteration while better models of the same hypothesis are still to come.
+        const int nm_h = nmodels[best_h];
+        for (int m = best_m + 1; m < nm_h; m++) {
+            const int c = counts[best_h * kMaxModels + m];
+            if (c > max(best, 4)) {
+                best = c;
+                best_m = m;
+                niters = d_ransac_update_num_iters(prob, (double)(n - best) / n, 5, niters);
+            }
+        }
+        hcur = best_h + 1;
+        mstart = 0;
     }
     if (lane == 0) {
         S.niters = niters;
