@@ -5,6 +5,8 @@
 #include <opencv2/core.hpp>
 
 #include <cstdio>
+#include <cstdlib>
+#include <string>
 #include <vector>
 using namespace cv;
 using namespace std;
@@ -23,8 +25,57 @@ Mat triangPoints(vector<Point2f>, vector<Point2f>, Mat, Mat, Mat) { return Mat()
 // ----
 #include "vo_mi355x_switch_end.hpp"
 
-int main(int argc, char**) {
+// `files a.bgr b.bgr rows cols dst_cols dst_rows fx fy cx cy k1 k2 p1 p2 out.txt`: the same call sequence on two raw BGR8 frames,
+// every output written with %a (exact) so that the test can compare it with the CPU oracle
+static int run_files(char** argv) {
+    const int rows = atoi(argv[4]), cols = atoi(argv[5]), dcols = atoi(argv[6]), drows = atoi(argv[7]);
+    Mat K(3, 3, CV_64F), dist(1, 4, CV_64F), R(3, 3, CV_64F), t(3, 1, CV_64F);
+    K.at<double>(0, 0) = atof(argv[8]), K.at<double>(1, 1) = atof(argv[9]), K.at<double>(0, 2) = atof(argv[10]), K.at<double>(1, 2) = atof(argv[11]);
+    K.at<double>(2, 2) = 1;
+    for (int i = 0; i < 4; i++) dist.at<double>(0, i) = atof(argv[12 + i]);
+    for (int i = 0; i < 3; i++) R.at<double>(i, i) = 1;
+    Mat img[2] = {Mat(rows, cols, CV_8UC3), Mat(rows, cols, CV_8UC3)};
+    for (int f = 0; f < 2; f++) {
+        FILE* fp = fopen(argv[2 + f], "rb");
+        if (!fp || fread(img[f].data, 1, (size_t)rows * cols * 3, fp) != (size_t)rows * cols * 3) return 2;
+        fclose(fp);
+    }
+    Mat prev_img = get_image(img[0], dcols, drows, K, dist), curr_img = get_image(img[1], dcols, drows, K, dist);
+    KpAsPoint2f_Match kP, inl;
+    opt_DetectFeatures(prev_img, curr_img, kP);
+    bool success = false;
+    if (kP.Kpoints1.size() >= 20) optRelativePose(kP, K, R, t, inl, success);
+    Mat wp;
+    if (success) wp = triangPoints(inl.Kpoints1, inl.Kpoints2, R, t, K);
+    FILE* fo = fopen(argv[16], "w");
+    if (!fo) return 3;
+    fprintf(fo, "gray %d %d\n", prev_img.rows, prev_img.cols);
+    unsigned long long h0 = 1469598103934665603ull, h1 = h0;  // FNV-1a of the two preprocessed frames
+    for (int r = 0; r < prev_img.rows; r++)
+        for (int c = 0; c < prev_img.cols; c++) {
+            h0 = (h0 ^ prev_img.data[r * prev_img.step + c]) * 1099511628211ull;
+            h1 = (h1 ^ curr_img.data[r * curr_img.step + c]) * 1099511628211ull;
+        }
+    fprintf(fo, "hash %llu %llu\n", h0, h1);
+    fprintf(fo, "matches %zu\n", kP.Kpoints1.size());
+    for (size_t i = 0; i < kP.Kpoints1.size(); i++)
+        fprintf(fo, "%a %a %a %a %d %d %a\n", kP.Kpoints1[i].x, kP.Kpoints1[i].y, kP.Kpoints2[i].x, kP.Kpoints2[i].y, kP.match[i].queryIdx,
+                kP.match[i].trainIdx, kP.match[i].distance);
+    fprintf(fo, "success %d inliers %zu\n", (int)success, inl.Kpoints1.size());
+    for (size_t i = 0; i < inl.Kpoints1.size(); i++)
+        fprintf(fo, "%a %a %a %a\n", inl.Kpoints1[i].x, inl.Kpoints1[i].y, inl.Kpoints2[i].x, inl.Kpoints2[i].y);
+    fprintf(fo, "R");
+    for (int i = 0; i < 9; i++) fprintf(fo, " %a", R.at<double>(i / 3, i % 3));
+    fprintf(fo, "\nt %a %a %a\n", t.at<double>(0, 0), t.at<double>(1, 0), t.at<double>(2, 0));
+    fprintf(fo, "world %d\n", wp.cols);
+    for (int j = 0; j < wp.cols; j++) fprintf(fo, "%a %a %a\n", wp.at<double>(0, j), wp.at<double>(1, j), wp.at<double>(2, j));
+    fclose(fo);
+    return 0;
+}
+
+int main(int argc, char** argv) {
     if (argc < 2) return 0;  // built and linked: enough without a GPU
+    if (argc >= 17 && std::string(argv[1]) == "files") return run_files(argv);
     // the call sequence of src/visual_Odometry.cpp:228-384 on a synthetic pair
     Mat K(3, 3, CV_64F), dist(1, 4, CV_64F), R(3, 3, CV_64F), t(3, 1, CV_64F);
     K.at<double>(0, 0) = K.at<double>(1, 1) = 400, K.at<double>(0, 2) = 320, K.at<double>(1, 2) = 240, K.at<double>(2, 2) = 1;

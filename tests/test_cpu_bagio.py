@@ -141,3 +141,183 @@ def test_rejects_what_it_cannot_read(tmp_path):
         bagio.BagReader(str(p))
     with pytest.raises(KeyError):
         bagio.MsgCodec("a/B", "unknown_pkg/Thing t\n").decode(b"\0" * 8)
+
+
+# ---- byte-level fixtures: every record type of the rosbag 2.0 specification, assembled from the specification's field tables
+# (NOT through BagWriter), including what the sequential reader used to pass over: index data (op 4) and chunk info (op 6)
+def _field(k, v):
+    return struct.pack("<I", len(k) + 1 + len(v)) + k + b"=" + v
+
+
+def _rec(fields, data):
+    h = b"".join(_field(k, v) for k, v in fields)
+    return struct.pack("<I", len(h)) + h + struct.pack("<I", len(data)) + data
+
+
+def _conn_record(cid, topic, mtype, definition):
+    hdr = _field(b"topic", topic) + _field(b"type", mtype) + _field(b"md5sum", b"0123456789abcdef0123456789abcdef") + \
+        _field(b"message_definition", definition) + _field(b"callerid", b"/recorder") + _field(b"latching", b"0")  # optional fields
+    return _rec([(b"conn", struct.pack("<I", cid)), (b"topic", topic), (b"op", b"\x07")], hdr)  # header fields in any order
+
+
+def _lz4_frame(payload: bytes, blocks) -> bytes:
+    """LZ4 frame around hand-made blocks: FLG = version 01, block-independent, content checksum; BD = 64 KiB blocks."""
+    import xxhash
+
+    flg, bd = 0b01100100, 0b01000000
+    hc = (xxhash.xxh32(bytes([flg, bd]), seed=0).intdigest() >> 8) & 0xFF
+    body = b"".join(struct.pack("<I", len(b) | (0x80000000 if stored else 0)) + b for b, stored in blocks)
+    return struct.pack("<I", 0x184D2204) + bytes([flg, bd, hc]) + body + struct.pack("<I", 0) + \
+        struct.pack("<I", xxhash.xxh32(payload, seed=0).intdigest())
+
+
+def test_lz4_block_and_frame_decoding_against_hand_made_streams():
+    # literals only
+    assert bagio.lz4_block_decode(bytes([0x50]) + b"hello") == b"hello"
+    # "abc" + match(offset 3, length 4 + 5 = 9, overlapping) + trailing literals "xyz!!" : token 0x35 / 0x50
+    blk = bytes([0x35]) + b"abc" + struct.pack("<H", 3) + bytes([0x50]) + b"xyz!!"
+    assert bagio.lz4_block_decode(blk) == b"abc" + b"abcabcabc" + b"xyz!!"
+    # long literal run (15 + 255 + 30 = 300) and long match (19 + 255 + 1 = 275 zeros from offset 1)
+    lit = bytes(range(256)) + bytes(44)
+    blk = bytes([0xFF, 255, 30]) + lit + struct.pack("<H", 1) + bytes([255, 1]) + bytes([0x10]) + b"E"
+    assert bagio.lz4_block_decode(blk) == lit + bytes([lit[-1]]) * 275 + b"E"
+    with pytest.raises(ValueError):
+        bagio.lz4_block_decode(bytes([0x04]) + struct.pack("<H", 9))  # offset before the start of the output
+    payload = b"abc" + b"abcabcabc" + b"xyz!!" + b"STORED-BLOCK"
+    frame = _lz4_frame(payload, [(bytes([0x35]) + b"abc" + struct.pack("<H", 3) + bytes([0x50]) + b"xyz!!", False), (b"STORED-BLOCK", True)])
+    assert bagio.lz4_frame_decode(frame) == payload
+    bad = bytearray(frame)
+    bad[-1] ^= 1
+    with pytest.raises(ValueError):
+        bagio.lz4_frame_decode(bytes(bad))  # content checksum
+
+
+def _handmade_bag(compression):
+    """Two chunks, two connections, index data after each chunk, index section with connection + chunk-info records."""
+    f32 = b"float32 data\n"
+    c0, c1 = _conn_record(0, b"/a", b"std_msgs/Float32", f32), _conn_record(1, b"/b", b"std_msgs/Float32", f32)
+
+    def msg(cid, sec, nsec, val):
+        return _rec([(b"op", b"\x02"), (b"time", struct.pack("<II", sec, nsec)), (b"conn", struct.pack("<I", cid))], struct.pack("<f", val))
+
+    chunks = [[(c0, None), (msg(0, 10, 999999999, 1.0), (0, 10, 999999999)), (c1, None), (msg(1, 11, 5, 2.0), (1, 11, 5)),
+               (msg(0, 11, 7, 3.0), (0, 11, 7))],
+              [(msg(1, 20, 0, 4.0), (1, 20, 0)), (msg(1, 21, 500, 5.0), (1, 21, 500))]]
+    body, infos = b"", []
+    pos = len(bagio.MAGIC) + 4096
+    for ch in chunks:
+        raw, index = b"", {}
+        for rec, key in ch:
+            if key is not None:
+                index.setdefault(key[0], []).append((key[1], key[2], len(raw)))
+            raw += rec
+        if compression == "none":
+            data = raw
+        elif compression == "bz2":
+            import bz2
+
+            data = bz2.compress(raw)
+        else:  # lz4: one stored block + the rest as a literal-only compressed block
+            half = len(raw) // 2
+            lit = raw[half:]
+            ll = len(lit)
+            tok = bytes([0xF0]) + b"\xff" * ((ll - 15) // 255) + bytes([(ll - 15) % 255]) if ll >= 15 else bytes([ll << 4])
+            data = _lz4_frame(raw, [(raw[:half], True), (tok + lit, False)])
+        crec = _rec([(b"op", b"\x05"), (b"compression", compression.encode()), (b"size", struct.pack("<I", len(raw)))], data)
+        irecs = b""
+        for cid, ent in index.items():
+            irecs += _rec([(b"op", b"\x04"), (b"ver", struct.pack("<I", 1)), (b"conn", struct.pack("<I", cid)), (b"count", struct.pack("<I", len(ent)))],
+                          b"".join(struct.pack("<III", s_, n_, o_) for s_, n_, o_ in ent))
+        times = [s_ * 10**9 + n_ for ent in index.values() for s_, n_, _ in ent]
+        infos.append((pos + len(body), min(times), max(times), {cid: len(ent) for cid, ent in index.items()}))
+        body += crec + irecs
+    index_pos = pos + len(body)
+    tail = c0 + c1
+    for cpos, t0, t1, counts in infos:
+        tail += _rec([(b"op", b"\x06"), (b"ver", struct.pack("<I", 1)), (b"chunk_pos", struct.pack("<Q", cpos)),
+                      (b"start_time", struct.pack("<II", t0 // 10**9, t0 % 10**9)), (b"end_time", struct.pack("<II", t1 // 10**9, t1 % 10**9)),
+                      (b"count", struct.pack("<I", len(counts)))], b"".join(struct.pack("<II", c, n) for c, n in counts.items()))
+    bh_fields = [(b"op", b"\x03"), (b"index_pos", struct.pack("<Q", index_pos)), (b"conn_count", struct.pack("<I", 2)), (b"chunk_count", struct.pack("<I", 2))]
+    h = b"".join(_field(k, v) for k, v in bh_fields)
+    pad = 4096 - 4 - len(h) - 4
+    bh = struct.pack("<I", len(h)) + h + struct.pack("<I", pad) + b" " * pad  # the bag header record is padded with spaces to 4096 bytes
+    return bagio.MAGIC + bh + body + tail, infos, chunks
+
+
+@pytest.mark.parametrize("compression", ["none", "bz2", "lz4"])
+def test_every_record_type_from_the_format_specification(tmp_path, compression):
+    blob, infos, chunks = _handmade_bag(compression)
+    path = tmp_path / "hand.bag"
+    path.write_bytes(blob)
+    bag = bagio.BagReader(str(path))
+    assert (bag.conn_count, bag.chunk_count) == (2, 2)
+    seq = [(t, c.id, float(st), st.ns, c.codec.decode(raw)["data"]) for t, c, st, raw in bag.messages()]
+    assert [(a, b, e) for a, b, _, _, e in seq] == [("/a", 0, 1.0), ("/b", 1, 2.0), ("/a", 0, 3.0), ("/b", 1, 4.0), ("/b", 1, 5.0)]
+    assert [d for _, _, _, d, _ in seq] == [10_999_999_999, 11_000_000_005, 11_000_000_007, 20_000_000_000, 21_000_000_500]  # exact integer times
+    # index section: connection records + chunk infos (op 6)
+    bag2 = bagio.BagReader(str(path))
+    assert bag2.read_index() == infos and sorted(bag2.connections) == [0, 1]
+    assert bag2.connections[1].topic == "/b" and bag2.connections[1].md5sum == "0123456789abcdef0123456789abcdef"
+    # index data records (op 4): offsets point at the message records inside the uncompressed chunk
+    for (cpos, _, _, counts), ch in zip(infos, chunks):
+        idx = bag2.chunk_index(cpos)
+        assert {c: len(e) for c, e in idx.items()} == counts
+        raw = b"".join(r for r, _ in ch)
+        for cid, ent in idx.items():
+            for t_ns, off in ent:
+                fields, _ = bagio._read_header(memoryview(raw), off)
+                assert fields["op"] == b"\x02" and struct.unpack("<I", fields["conn"])[0] == cid
+                s_, n_ = struct.unpack("<II", fields["time"])
+                assert s_ * 10**9 + n_ == t_ns
+    # indexed access: by topic and by time range, skipping chunks the chunk infos rule out
+    assert [c.codec.decode(r)["data"] for _, c, _, r in bag2.messages_indexed(["/a"])] == [1.0, 3.0]
+    assert [c.codec.decode(r)["data"] for _, c, _, r in bag2.messages_indexed(None, start=11.0, end=20.5)] == [2.0, 3.0, 4.0]
+    assert [c.codec.decode(r)["data"] for _, c, _, r in bag2.messages_indexed(["/b"], start=15.0)] == [4.0, 5.0]
+    # an unclosed bag (index_pos = 0) still reads sequentially, but has no index section
+    open_blob = bytearray(blob)
+    ip = bytes(open_blob).index(b"index_pos=") + len(b"index_pos=")
+    open_blob[ip : ip + 8] = struct.pack("<Q", 0)
+    p2 = tmp_path / "open.bag"
+    p2.write_bytes(bytes(open_blob))
+    b3 = bagio.BagReader(str(p2))
+    assert len(list(b3.messages())) == 5
+    with pytest.raises(ValueError):
+        b3.read_index()
+
+
+def test_writer_chunk_infos_are_in_time_order_across_a_second_boundary(tmp_path):
+    """The writer's chunk infos (used by messages_indexed) order times by (sec, nsec), not by the packed word."""
+    path = str(tmp_path / "w.bag")
+    w = bagio.BagWriter(path, "none", chunk_bytes=1 << 20)
+    w.add_connection("/x", "std_msgs/Float32", "float32 data\n")
+    for t, v in ((100.9, 1.0), (101.0001, 2.0), (101.5, 3.0)):
+        w.write("/x", t, struct.pack("<f", v))
+    w.close()
+    bag = bagio.BagReader(path)
+    (pos, t0, t1, counts), = bag.read_index()
+    assert t0 == 100_900_000_000 and t1 == 101_500_000_000 and counts == {0: 3}
+    assert [c.codec.decode(r)["data"] for _, c, _, r in bag.messages_indexed(["/x"], start=101.0)] == [2.0, 3.0]
+
+
+def test_stamps_keep_integer_nanoseconds(tmp_path):
+    """Header stamps at epoch scale: the float form resolves ~0.2 us, the (sec, nsec) pair is exact; read_sequence can return
+    seconds since the first frame computed from the integers (what the replay's dt uses)."""
+    c = bagio.MsgCodec("marta_msgs/Altitude", ALT_DEF)
+    raw = struct.pack("<III", 1, 1_700_000_000, 123_456_789) + struct.pack("<I", 0) + struct.pack("<f", 1.0) + b"\x00"
+    st = c.decode(raw)["header"]["stamp"]
+    assert isinstance(st, float) and (st.sec, st.nsec) == (1_700_000_000, 123_456_789) and st.ns == 1_700_000_000_123_456_789
+    assert c.encode(c.decode(raw)) == raw  # the pair survives a round trip bit for bit (the float alone would not)
+    path = str(tmp_path / "s.bag")
+    w = bagio.BagWriter(path)
+    w.add_connection("/pylon_camera/image_raw/compressed", "sensor_msgs/CompressedImage", bagio.COMPRESSED_IMAGE_DEF)
+    ci = bagio.MsgCodec("sensor_msgs/CompressedImage", bagio.COMPRESSED_IMAGE_DEF)
+    img = np.zeros((8, 8, 3), np.uint8)
+    for i, nsec in enumerate((999_999_999, 100_000_001, 200_000_003)):
+        sec = 1_700_000_000 + (0 if i == 0 else 1)
+        w.write("/pylon_camera/image_raw/compressed", 5.0 + i, ci.encode({"header": {"seq": i, "stamp": bagio.Stamp(sec, nsec), "frame_id": ""},
+                                                                            "format": "png", "data": _png(img)}))
+    w.close()
+    _, rel, _ = bagio.read_sequence(path, relative_stamps=True)
+    assert rel.tolist() == [0.0, 100_000_002 * 1e-9, 200_000_004 * 1e-9]
+    _, ab, _ = bagio.read_sequence(path)
+    assert abs((ab[1] - ab[0]) - 0.100000002) > 1e-9  # what the float form alone would give: off by more than a nanosecond

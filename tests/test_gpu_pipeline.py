@@ -232,18 +232,94 @@ def test_bag_to_poses_end_to_end(ctx, tmp_path):
     assert _angle(recs[0]["R"], Rgt) < 1.0
 
 
-def test_cv_adaptor_runs_the_node_call_sequence():
-    """N3: the switch headers + cv::Mat adaptor (mock cv types) run get_image -> opt_DetectFeatures -> optRelativePose ->
-    triangPoints as src/visual_Odometry.cpp:228-384 calls them.  The binary is built by __graft_entry__.build()."""
+def _adaptor_exe():
     import os
-    import subprocess
 
     exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "cv_adaptor_check")
     if not os.path.exists(exe):
         pytest.fail("examples/cv_adaptor_check missing: run __graft_entry__.build()")
-    out = subprocess.run([exe, "run"], capture_output=True, text=True, timeout=120)
+    return exe
+
+
+def test_cv_adaptor_runs_the_node_call_sequence():
+    """N3: the switch headers + cv::Mat adaptor (mock cv types) run get_image -> opt_DetectFeatures -> optRelativePose ->
+    triangPoints as src/visual_Odometry.cpp:228-384 calls them.  The binary is built by __graft_entry__.build()."""
+    import subprocess
+
+    out = subprocess.run([_adaptor_exe(), "run"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "success 1" in out.stdout, out.stdout
+
+
+def test_cv_adaptor_outputs_equal_the_oracle(tmp_path):
+    """N3 against the oracle, not just `success 1`: two colour frames through the node's call sequence on the adaptor (the
+    reference's four signatures on cv:: types) must give the oracle's preprocessed frames, matches, inliers, pose and world
+    points - get_image = oracle_prep, opt_DetectFeatures = O.detect_match (bit for bit), optRelativePose = O.relative_pose,
+    triangPoints = O.triang_points."""
+    import subprocess
+
+    from visual_odometry_amd._abi import VoPrepParams
+
+    sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 1001)
+    rng = np.random.default_rng(5)
+    frames = []
+    for g in (sc.img1, sc.img2):  # colour frames whose channels differ, so that the BGR weighting of get_image matters
+        bgr = np.stack([g, np.clip(g.astype(np.int16) + rng.integers(-6, 7, g.shape), 0, 255).astype(np.uint8),
+                        np.clip(g.astype(np.int16) // 2 + 40, 0, 255).astype(np.uint8)], axis=2)
+        frames.append(np.ascontiguousarray(bgr))
+    dist = np.array([0.02, -0.01, 0.001, -0.0005])
+    K = synth.K_PARETE
+    files = []
+    for i, f in enumerate(frames):
+        path = tmp_path / f"f{i}.bgr"
+        f.tofile(path)
+        files.append(str(path))
+    out_txt = str(tmp_path / "out.txt")
+    args = [_adaptor_exe(), "files", files[0], files[1], "480", "640", "640", "480", repr(K[0, 0]), repr(K[1, 1]), repr(K[0, 2]), repr(K[1, 2])]
+    args += [repr(float(d)) for d in dist] + [out_txt]
+    run = subprocess.run(args, capture_output=True, text=True, timeout=120)
+    assert run.returncode == 0, run.stdout + run.stderr
+    lines = open(out_txt).read().split("\n")
+    hx = float.fromhex
+    # the oracle on the same frames
+    pp = VoPrepParams()
+    pp.src_rows, pp.src_cols, pp.dst_rows, pp.dst_cols = 480, 640, 480, 640
+    pp.K[:] = list(K.ravel())
+    pp.dist[:] = list(dist)
+    pp.clip_limit, pp.tiles_x, pp.tiles_y = 16.0, 8, 8
+    g0, g1 = O.prep(pp, frames[0])["gray"], O.prep(pp, frames[1])["gray"]
+
+    def fnv(a):
+        h = 1469598103934665603
+        for v in a.ravel().tolist():
+            h = ((h ^ v) * 1099511628211) & (2**64 - 1)
+        return h
+
+    assert lines[0] == "gray 480 640"
+    assert lines[1] == f"hash {fnv(g0)} {fnv(g1)}"  # get_image
+    n = int(lines[2].split()[1])
+    rows = [ln.split() for ln in lines[3 : 3 + n]]
+    p1 = np.array([[hx(r[0]), hx(r[1])] for r in rows], np.float32)
+    p2 = np.array([[hx(r[2]), hx(r[3])] for r in rows], np.float32)
+    rp1, rp2, rm = O.detect_match(g0, g1)
+    assert n == len(rm) and n > 100
+    assert np.array_equal(p1, rp1) and np.array_equal(p2, rp2)
+    assert [int(r[4]) for r in rows] == rm["queryIdx"].tolist() and [int(r[5]) for r in rows] == rm["trainIdx"].tolist()
+    assert np.array_equal(np.array([hx(r[6]) for r in rows], np.float32), rm["distance"])
+    head = lines[3 + n].split()
+    ok, ni = int(head[1]), int(head[3])
+    st, R, t, i1, i2, rok = O.relative_pose(rp1, rp2, K)
+    assert ok == int(rok) == 1 and ni == len(i1)
+    irows = [ln.split() for ln in lines[4 + n : 4 + n + ni]]
+    assert np.array_equal(np.array([[hx(r[0]), hx(r[1])] for r in irows], np.float32), i1)
+    assert np.array_equal(np.array([[hx(r[2]), hx(r[3])] for r in irows], np.float32), i2)
+    Rg = np.array([hx(v) for v in lines[4 + n + ni].split()[1:]]).reshape(3, 3)
+    tg = np.array([hx(v) for v in lines[5 + n + ni].split()[1:]])
+    assert np.abs(Rg - R).max() < 1e-9 and np.abs(tg - t).max() < 1e-9
+    nw = int(lines[6 + n + ni].split()[1])
+    Xg = np.array([[hx(v) for v in ln.split()] for ln in lines[7 + n + ni : 7 + n + ni + nw]]).T
+    Xr = O.triang_points(i1, i2, R, t, K)
+    assert Xg.shape == Xr.shape and nw > 50 and np.allclose(Xg, Xr, rtol=1e-5, atol=1e-6)
 
 
 def test_back_to_back_runs_with_new_inputs_in_between(ctx):

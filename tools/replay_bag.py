@@ -40,7 +40,8 @@ def main():
         frames, stamps = frames[:a.max_frames], stamps[:a.max_frames]
         alts = np.full(len(frames), a.altitude if a.altitude is not None else 1.0)
     else:
-        frames, stamps, alts = bagio.read_sequence(a.source, a.image_topic, a.altitude_topic, max_frames=a.max_frames)
+        frames, stamps, alts = bagio.read_sequence(a.source, a.image_topic, a.altitude_topic, max_frames=a.max_frames,
+                                                     relative_stamps=True)  # exact dt from the integer (sec, nsec) stamps
         if a.altitude is not None:
             alts = np.full(len(frames), a.altitude)
     if len(frames) < 2:

@@ -3,7 +3,9 @@
 The reference is driven by `rosbag play` (launch/*.launch:8; the bags themselves are not in the repository): camera frames
 arrive as sensor_msgs/CompressedImage on /pylon_camera/image_raw/compressed and the scale comes from marta_msgs/Altitude on
 /drivers/altitude (src/visual_Odometry.cpp:190-196).  This module reads the rosbag 2.0 container directly (records,
-chunks with `none` or `bz2` compression, connection records), deserialises ANY message type from the message definition
+chunks with `none`, `bz2` or `lz4` compression, connection, index-data and chunk-info records: sequentially, or through the
+index section at `index_pos` so that chunks outside a time range / without a wanted topic are never decompressed),
+deserialises ANY message type from the message definition
 text each connection carries (so marta_msgs needs no generated code), decodes JPEG / PNG payloads with Pillow on the host,
 and returns what visual_odometry_amd.replay.replay() takes.  `BagWriter` exists for tests and for making small fixtures.
 
@@ -27,6 +29,114 @@ _PRIM = {"bool": "?", "int8": "b", "uint8": "B", "byte": "b", "char": "B", "int1
          "uint32": "I", "int64": "q", "uint64": "Q", "float32": "f", "float64": "d"}
 
 HEADER_DEF = "uint32 seq\ntime stamp\nstring frame_id\n"
+
+
+class Stamp(float):
+    """A ROS time as seconds (a float, ~0.2 us resolution at epoch scale) that also keeps the integer (sec, nsec) it was read
+    from: differences of stamps - the node's dt, visual_Odometry.cpp:470 - should be taken with `ns`, which is exact."""
+
+    def __new__(cls, sec: int, nsec: int):
+        obj = super().__new__(cls, sec + nsec * 1e-9)
+        obj.sec, obj.nsec = int(sec), int(nsec)
+        return obj
+
+    @property
+    def ns(self) -> int:
+        return self.sec * 1_000_000_000 + self.nsec
+
+
+# ------------------------------------------------------------------------------------------------ LZ4 (chunk compression "lz4")
+def lz4_block_decode(src, max_out: int | None = None) -> bytes:
+    """One LZ4 block (the sequence format of the LZ4 block specification): token = literal length << 4 | match length - 4,
+    lengths of 15 continue in 255-valued bytes, little-endian 16-bit match offset; matches may overlap their own output."""
+    src = bytes(src)
+    out = bytearray()
+    i, n = 0, len(src)
+    while i < n:
+        tok = src[i]
+        i += 1
+        ll = tok >> 4
+        if ll == 15:
+            while True:
+                b = src[i]
+                i += 1
+                ll += b
+                if b != 255:
+                    break
+        out += src[i : i + ll]
+        i += ll
+        if i >= n:
+            break  # the last sequence has literals only
+        off = src[i] | (src[i + 1] << 8)
+        i += 2
+        if off == 0 or off > len(out):
+            raise ValueError("lz4: match offset outside the decoded data")
+        ml = (tok & 15) + 4
+        if (tok & 15) == 15:
+            while True:
+                b = src[i]
+                i += 1
+                ml += b
+                if b != 255:
+                    break
+        start = len(out) - off
+        if off >= ml:
+            out += out[start : start + ml]
+        else:  # overlapping match: the pattern of `off` bytes repeats
+            pat = bytes(out[start:])
+            out += (pat * (ml // off + 1))[:ml]
+        if max_out is not None and len(out) > max_out:
+            raise ValueError("lz4: block larger than declared")
+    return bytes(out)
+
+
+def lz4_frame_decode(src) -> bytes:
+    """LZ4 frame format (magic 0x184D2204; what roslz4 writes into `lz4` chunks and the lz4 command line tool reads): FLG / BD /
+    optional content size and dictionary id / header checksum, then blocks (size word, high bit = stored uncompressed, optional
+    block checksum) up to the end mark, optional xxhash32 content checksum (verified when the xxhash module is present)."""
+    mv = memoryview(bytes(src))
+    if len(mv) < 7 or struct.unpack_from("<I", mv, 0)[0] != 0x184D2204:
+        raise ValueError("lz4: not an LZ4 frame")
+    flg, bd = mv[4], mv[5]
+    if (flg >> 6) != 1:
+        raise ValueError("lz4: unsupported frame version")
+    block_checksum, content_size, content_checksum, dict_id = (flg >> 4) & 1, (flg >> 3) & 1, (flg >> 2) & 1, flg & 1
+    block_max = {4: 1 << 16, 5: 1 << 18, 6: 1 << 20, 7: 1 << 22}.get((bd >> 4) & 7)
+    if block_max is None:
+        raise ValueError("lz4: bad block size code")
+    off = 6
+    declared = None
+    if content_size:
+        declared = struct.unpack_from("<Q", mv, off)[0]
+        off += 8
+    if dict_id:
+        off += 4
+    off += 1  # header checksum byte
+    out = bytearray()
+    while True:
+        size = struct.unpack_from("<I", mv, off)[0]
+        off += 4
+        if size == 0:
+            break
+        stored = bool(size >> 31)
+        size &= 0x7FFFFFFF
+        data = mv[off : off + size]
+        if len(data) != size:
+            raise ValueError("lz4: truncated block")
+        off += size + (4 if block_checksum else 0)
+        out += bytes(data) if stored else lz4_block_decode(data, block_max)
+    if content_checksum:
+        want = struct.unpack_from("<I", mv, off)[0]
+        try:
+            import xxhash
+
+            if xxhash.xxh32(bytes(out), seed=0).intdigest() != want:
+                raise ValueError("lz4: content checksum mismatch")
+        except ImportError:
+            pass
+    if declared is not None and declared != len(out):
+        raise ValueError("lz4: content size mismatch")
+    return bytes(out)
 
 
 # ------------------------------------------------------------------------------------------------ message definitions
@@ -87,8 +197,11 @@ class MsgCodec:
         if ftype == "string":
             n = struct.unpack_from("<I", mv, off)[0]
             return bytes(mv[off + 4:off + 4 + n]).decode("utf-8", "replace"), off + 4 + n
-        if ftype in ("time", "duration"):
-            s, ns = struct.unpack_from("<II" if ftype == "time" else "<ii", mv, off)
+        if ftype == "time":
+            s, ns = struct.unpack_from("<II", mv, off)
+            return Stamp(s, ns), off + 8
+        if ftype == "duration":
+            s, ns = struct.unpack_from("<ii", mv, off)
             return s + ns * 1e-9, off + 8
         return self._dec_type(self._resolve(ftype, scope), mv, off)
 
@@ -130,8 +243,12 @@ class MsgCodec:
             raw = v.encode("utf-8")
             b.write(struct.pack("<I", len(raw)) + raw)
         elif ftype in ("time", "duration"):
-            s = int(np.floor(v))
-            b.write(struct.pack("<II" if ftype == "time" else "<ii", s, int(round((v - s) * 1e9))))
+            if isinstance(v, Stamp):
+                s, ns = v.sec, v.nsec
+            else:
+                s = int(np.floor(v))
+                ns = int(round((v - s) * 1e9))
+            b.write(struct.pack("<II" if ftype == "time" else "<ii", s, ns))
         else:
             self._enc_type(self._resolve(ftype, scope), v, b)
 
@@ -212,7 +329,22 @@ class BagReader:
             hdr, _ = _read_header(memoryview(struct.pack("<I", len(data)) + bytes(data)), 0)
             self.connections[cid] = Connection(cid, fields["topic"].decode(), hdr)
 
-    def _scan(self, mv, off, end, topics):
+    @staticmethod
+    def _chunk_payload(fields, data):
+        comp = fields["compression"].decode()
+        if comp == "none":
+            inner = data
+        elif comp == "bz2":
+            inner = memoryview(bz2.decompress(bytes(data)))
+        elif comp == "lz4":
+            inner = memoryview(lz4_frame_decode(data))
+        else:
+            raise NotImplementedError(f"chunk compression '{comp}' (none, bz2 and lz4 are what rosbag writes)")
+        if "size" in fields and struct.unpack("<I", fields["size"])[0] != len(inner):
+            raise ValueError("chunk: uncompressed size does not match the record's `size` field")
+        return inner
+
+    def _scan(self, mv, off, end, topics, t_lo=None, t_hi=None):
         for fields, data in _records(mv, off, end):
             op = fields["op"][0]
             if op == OP_CONNECTION:
@@ -220,17 +352,75 @@ class BagReader:
             elif op == OP_MSG:
                 conn = self.connections[struct.unpack("<I", fields["conn"])[0]]
                 if topics is None or conn.topic in topics:
-                    s, ns = struct.unpack("<II", fields["time"])
-                    yield conn.topic, conn, s + ns * 1e-9, bytes(data)
+                    st = Stamp(*struct.unpack("<II", fields["time"]))
+                    if (t_lo is None or st.ns >= t_lo) and (t_hi is None or st.ns <= t_hi):
+                        yield conn.topic, conn, st, bytes(data)
             elif op == OP_CHUNK:
-                comp = fields["compression"].decode()
-                if comp == "none":
-                    inner = data
-                elif comp == "bz2":
-                    inner = memoryview(bz2.decompress(bytes(data)))
-                else:
-                    raise NotImplementedError(f"chunk compression '{comp}' (only none and bz2)")
-                yield from self._scan(inner, 0, len(inner), topics)
+                inner = self._chunk_payload(fields, data)
+                yield from self._scan(inner, 0, len(inner), topics, t_lo, t_hi)
+            # OP_INDEX / OP_CHUNK_INFO records carry no messages: the sequential scan passes over them (any other op code,
+            # e.g. from a later format revision, is skipped the same way: a record is self-delimiting)
+
+    # ---- the index section (everything from index_pos on: one connection record per connection, one chunk-info per chunk)
+    def read_index(self):
+        """Connection records and chunk infos from the index section: [(chunk_pos, start_ns, end_ns, {conn: count}), ...] in
+        file order.  Raises if the bag was not closed (index_pos = 0: `rosbag reindex` territory; messages() still works)."""
+        if self.index_pos == 0:
+            raise ValueError("bag has no index section (index_pos = 0: not closed / needs reindexing)")
+        mv = memoryview(self.data)
+        infos = []
+        for fields, data in _records(mv, self.index_pos, len(mv)):
+            op = fields["op"][0]
+            if op == OP_CONNECTION:
+                self._add_connection(fields, data)
+            elif op == OP_CHUNK_INFO:
+                if struct.unpack("<I", fields["ver"])[0] != 1:
+                    raise NotImplementedError("chunk info version != 1")
+                n = struct.unpack("<I", fields["count"])[0]
+                counts = dict(struct.unpack_from("<II", data, 8 * i) for i in range(n))
+                t0 = Stamp(*struct.unpack("<II", fields["start_time"])).ns
+                t1 = Stamp(*struct.unpack("<II", fields["end_time"])).ns
+                infos.append((struct.unpack("<Q", fields["chunk_pos"])[0], t0, t1, counts))
+        return infos
+
+    def chunk_index(self, chunk_pos: int):
+        """The index-data records (op 4, version 1) that follow the chunk at chunk_pos: {conn: [(time_ns, offset in the
+        uncompressed chunk), ...]}."""
+        mv = memoryview(self.data)
+        recs = _records(mv, chunk_pos, len(mv))
+        fields, _ = next(recs)
+        if fields["op"][0] != OP_CHUNK:
+            raise ValueError("no chunk record at this position")
+        out = {}
+        for fields, data in recs:
+            if fields["op"][0] != OP_INDEX:
+                break
+            if struct.unpack("<I", fields["ver"])[0] != 1:
+                raise NotImplementedError("index data version != 1")
+            n = struct.unpack("<I", fields["count"])[0]
+            ent = []
+            for i in range(n):
+                s_, ns_, off_ = struct.unpack_from("<III", data, 12 * i)
+                ent.append((s_ * 1_000_000_000 + ns_, off_))
+            out[struct.unpack("<I", fields["conn"])[0]] = ent
+        return out
+
+    def messages_indexed(self, topics=None, start=None, end=None):
+        """As messages(), but through the index section: only chunks that hold a wanted connection and overlap [start, end]
+        (seconds, bag receive time) are read and decompressed."""
+        infos = self.read_index()
+        want = None if topics is None else {c.id for c in self.connections.values() if c.topic in set(topics)}
+        t_lo = None if start is None else int(round(start * 1e9))
+        t_hi = None if end is None else int(round(end * 1e9))
+        mv = memoryview(self.data)
+        for pos, t0, t1, counts in infos:
+            if want is not None and not (want & set(counts)):
+                continue
+            if (t_lo is not None and t1 < t_lo) or (t_hi is not None and t0 > t_hi):
+                continue
+            fields, data = next(_records(mv, pos, len(mv)))
+            inner = self._chunk_payload(fields, data)
+            yield from self._scan(inner, 0, len(inner), None if topics is None else set(topics), t_lo, t_hi)
 
     def messages(self, topics=None):
         mv = memoryview(self.data)
@@ -307,7 +497,7 @@ class BagWriter:
             data = b"".join(struct.pack("<QI", tt, off) for tt, off, _ in entries)
             self.f.write(self._rec({"op": bytes([OP_INDEX]), "ver": struct.pack("<I", 1), "conn": struct.pack("<I", cid),
                                     "count": struct.pack("<I", len(entries))}, data))
-            times += [tt for tt, _, _ in entries]
+            times += [(tt & 0xFFFFFFFF) * 1_000_000_000 + (tt >> 32) for tt, _, _ in entries]  # (sec, nsec) words -> nanoseconds
         self.chunk_infos.append((pos, min(times), max(times), {c: len(e) for c, e in self.chunk_index.items()}))
         self.chunk, self.chunk_index = io.BytesIO(), {}
 
@@ -319,7 +509,8 @@ class BagWriter:
         for pos, t0, t1, counts in self.chunk_infos:
             data = b"".join(struct.pack("<II", c, n) for c, n in counts.items())
             self.f.write(self._rec({"op": bytes([OP_CHUNK_INFO]), "ver": struct.pack("<I", 1), "chunk_pos": struct.pack("<Q", pos),
-                                    "start_time": struct.pack("<Q", t0), "end_time": struct.pack("<Q", t1),
+                                    "start_time": struct.pack("<II", t0 // 1_000_000_000, t0 % 1_000_000_000),
+                                    "end_time": struct.pack("<II", t1 // 1_000_000_000, t1 % 1_000_000_000),
                                     "count": struct.pack("<I", len(counts))}, data))
         self._write_bag_header(index_pos, len(self.conns), len(self.chunk_infos))
         self.f.close()
@@ -351,7 +542,7 @@ def decode_image(msg: dict, msg_type: str) -> np.ndarray:
 
 
 def read_sequence(path, image_topic="/pylon_camera/image_raw/compressed", altitude_topic="/drivers/altitude", altitude_field="altitude",
-                  max_frames=None, use_header_stamp=True):
+                  max_frames=None, use_header_stamp=True, relative_stamps=False):
     """Frames, stamps [s] and the latest altitude at each frame, in bag order - the node's view of its topics
     (it keeps the latest message of every topic, src/visual_Odometry.cpp:112-177)."""
     bag = BagReader(path)
@@ -367,7 +558,12 @@ def read_sequence(path, image_topic="/pylon_camera/image_raw/compressed", altitu
         alts.append(last_alt)
         if max_frames is not None and len(frames) >= max_frames:
             break
-    return frames, np.array(stamps), np.array(alts)
+    if relative_stamps:
+        # seconds since the first frame, from the integer (sec, nsec) pairs: exact differences (the float form of an epoch
+        # stamp resolves only ~0.2 us), which is what the replay's dt needs
+        ns = np.array([st.ns for st in stamps], np.int64)
+        return frames, (ns - ns[0]) * 1e-9 if len(ns) else np.zeros(0), np.array(alts)
+    return frames, np.array([float(st) for st in stamps]), np.array(alts)
 
 
 def read_image_dir(path, fps=10.0, exts=(".png", ".jpg", ".jpeg", ".bmp", ".pgm", ".ppm")):
