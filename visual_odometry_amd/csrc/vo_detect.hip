@@ -316,17 +316,140 @@ __global__ __launch_bounds__(1024) void k_integral(const uint8_t* __restrict__ i
     }
 }
 
+// Inclusive prefix sum over the 64 lanes of a wavefront with data-parallel-primitive adds (no LDS traffic, unlike the
+// ds_bpermute behind __shfl_up): four shifts inside the 16-lane rows, then lane 15 of every row into the next row (rows 1
+// and 3), then lane 31 into rows 2 and 3.  Lanes that a step does not write add the `old` operand, 0.
+__device__ __forceinline__ int wave_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, true);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, true);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, true);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, true);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, true);  // row_bcast:15, rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, true);  // row_bcast:31, rows 2 and 3
+    return v;
+}
+
+struct __attribute__((packed, aligned(4))) Int4U {  // four consecutive ints at a 4-byte aligned address (sum rows have an odd pitch)
+    int v[4];
+};
+
+// Frames whose rows are 4-byte aligned (W and the frame pitch multiples of four): four columns per lane from ONE aligned word
+// per row (the byte loads of k_integral<CPT> run at the texture addresser's 4 lanes per clock: 2.3 TB/s), the row scan on DPP
+// adds, one 16-byte store per lane and row.  A workgroup takes one 16-row band; frames wider than NT * 4 columns go through
+// it in column chunks, the row sums carried from chunk to chunk.
+template <int NT, bool MULTI>
+__global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_integral4(const uint8_t* __restrict__ img, size_t img_stride, int H, int W, int nbands,
+                                                  const int32_t* __restrict__ colsum, int32_t* __restrict__ sum, size_t sum_stride) {
+    constexpr int NWV = NT / 64;
+    __shared__ int32_t s_wtot[kBand][NWV + 1];  // per row: the wavefronts' totals, then (after the second-level scan) their
+                                                // exclusive prefixes and, in the last slot, the row's chunk total
+    static_assert(kBand * NWV <= NT, "second-level scan: one lane per (row, wavefront)");
+    const int frame = blockIdx.y, band = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sw = W + 1;
+    const uint8_t* im = img + (size_t)frame * img_stride;
+    int32_t* out = sum + (size_t)frame * sum_stride;
+    const int32_t* cs = colsum + ((size_t)frame * nbands + band) * W;
+    if (band == 0)
+        for (int x = tid; x < sw; x += NT) out[x] = 0;
+    int32_t chunk_carry[MULTI ? kBand : 1];  // sum of the row's pixels left of the current chunk (frames wider than NT * 4)
+#pragma unroll
+    for (int r = 0; r < (MULTI ? kBand : 1); r++) chunk_carry[r] = 0;
+    for (int xc = 0; xc < (MULTI ? W : 1); xc += NT * 4) {
+        const int x = xc + tid * 4;
+        const bool live = x < W;
+        // column sums of all rows above this band (k_colsum_scan made them exclusive prefixes over the bands)
+        int4 carry = make_int4(0, 0, 0, 0);
+        if (live) carry = *reinterpret_cast<const int4*>(cs + x);
+        uint32_t px[kBand];
+#pragma unroll
+        for (int r = 0; r < kBand; r++) {
+            const int y = band * kBand + r;
+            px[r] = (live && y < H) ? *reinterpret_cast<const uint32_t*>(im + (size_t)y * W + x) : 0u;
+        }
+        // pass 1: the lane's row totals and their scan.  Only the packed pixels and the scan results stay in registers (the
+        // kernel has to fit beside the geometry kernels of the previous run, which fill most of the register files); pass 2
+        // re-runs the cheap column adds from the saved carry.
+        const int4 carry0 = carry;
+        int32_t excl[kBand];  // exclusive prefix of the lanes' totals within the wavefront
+#pragma unroll
+        for (int r = 0; r < kBand; r++) {
+            carry.x += (int)(px[r] & 255u);
+            carry.y += (int)((px[r] >> 8) & 255u);
+            carry.z += (int)((px[r] >> 16) & 255u);
+            carry.w += (int)(px[r] >> 24);
+            const int tot = live ? (carry.x + carry.y) + (carry.z + carry.w) : 0;
+            const int inc = wave_incl_scan(tot);
+            excl[r] = inc - tot;
+            if (lane == 63) s_wtot[r][wave] = inc;
+        }
+        __syncthreads();
+        if (tid < kBand) {  // second-level scan: one lane per row walks the row's NWV totals
+            int32_t run = 0;
+#pragma unroll
+            for (int w = 0; w < NWV; w++) {
+                const int32_t t = s_wtot[tid][w];
+                s_wtot[tid][w] = run;
+                run += t;
+            }
+            s_wtot[tid][NWV] = run;
+        }
+        __syncthreads();
+        carry = carry0;
+#pragma unroll
+        for (int r = 0; r < kBand; r++) {
+            const int y = band * kBand + r;
+            carry.x += (int)(px[r] & 255u);
+            carry.y += (int)((px[r] >> 8) & 255u);
+            carry.z += (int)((px[r] >> 16) & 255u);
+            carry.w += (int)(px[r] >> 24);
+            int32_t off = excl[r] + s_wtot[r][wave];
+            if (MULTI) {
+                off += chunk_carry[r];
+                chunk_carry[r] += s_wtot[r][NWV];
+            }
+            if (y < H) {
+                int32_t* row = out + (size_t)(y + 1) * sw;
+                if (xc == 0 && tid == 0) row[0] = 0;
+                if (live) {
+                    Int4U o;
+                    o.v[0] = carry.x + off;
+                    o.v[1] = o.v[0] + carry.y;
+                    o.v[2] = o.v[1] + carry.z;
+                    o.v[3] = o.v[2] + carry.w;
+                    *reinterpret_cast<Int4U*>(row + x + 1) = o;
+                }
+            }
+        }
+        __syncthreads();  // s_wtot is rewritten by the next chunk
+    }
+}
+
 int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs) {
     StageScope sc(ctx, ST_INTEGRAL);
     const int nbands = (fs.H + kBand - 1) / kBand;
     dim3 g1((fs.W + 255) / 256, nbands, fs.F);
-    if (fs.W % 4 == 0 && fs.img_stride() % 4 == 0)
+    const bool aligned4 = fs.W % 4 == 0 && fs.img_stride() % 4 == 0;
+    if (aligned4)
         hipLaunchKernelGGL(k_colsum4, dim3((fs.W / 4 + 255) / 256, nbands, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                            fs.H, fs.W, nbands, fs.colsum);
     else
         hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
     hipLaunchKernelGGL(k_colsum_scan, dim3((fs.W + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.W, nbands, fs.colsum);
     dim3 g2(nbands, fs.F);
+    if (aligned4) {
+        if (fs.W <= 1024)
+            hipLaunchKernelGGL((k_integral4<256, false>), g2, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
+                               fs.sum, fs.sum_stride());
+        else if (fs.W <= 2048)
+            hipLaunchKernelGGL((k_integral4<512, false>), g2, dim3(512), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
+                               fs.sum, fs.sum_stride());
+        else
+            hipLaunchKernelGGL((k_integral4<512, true>), g2, dim3(512), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
+                               fs.sum, fs.sum_stride());
+        VO_HIP(hipGetLastError());
+        return VO_OK;
+    }
     const int cpt = (fs.W + 1023) / 1024;
 #define LAUNCH_INT(C)                                                                                              \
     hipLaunchKernelGGL(k_integral<C>, g2, dim3(1024), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, \

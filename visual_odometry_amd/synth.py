@@ -355,8 +355,12 @@ def sequence_c3(n_frames: int = 512, seed: int = 3003, h: int = 505, w: int = 64
     if workers > 1:
         import multiprocessing as mp
 
-        with mp.get_context("spawn").Pool(workers, initializer=_c3_init, initargs=(world,)) as pool:
+        pool = mp.get_context("spawn").Pool(workers, initializer=_c3_init, initargs=(world,))
+        try:
             frames = pool.map(_c3_frame, range(n_frames), chunksize=max(1, n_frames // (4 * workers)))
+        finally:
+            pool.close()  # workers leave by themselves (a terminate() under a profiler's signal handler can hang)
+            pool.join()
     else:
         _c3_init(world)
         frames = [_c3_frame(k) for k in range(n_frames)]
