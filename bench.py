@@ -126,7 +126,8 @@ def main():
 
     ndev = torch.cuda.device_count()
     backend = os.environ.get("VO_BENCH_BACKEND", "nccl" if ndev >= world else "gloo")
-    if world > 1:
+    use_dist = world > 1 or "RANK" in os.environ  # under torchrun even a single rank goes through the process group (RCCL)
+    if use_dist:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -137,7 +138,7 @@ def main():
             dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
-    coll_dev = "cuda" if world > 1 and backend == "nccl" else "cpu"
+    coll_dev = "cuda" if use_dist and backend == "nccl" else "cpu"
     dev = local_rank % max(ndev, 1)
     torch.cuda.set_device(dev)
 
@@ -160,12 +161,12 @@ def main():
             batch.set_pair(i, img1, img2, K)
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
     def max_over_ranks(dt):
-        if world > 1:
+        if use_dist:
             tmax = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             return float(tmax.item())
@@ -191,7 +192,7 @@ def main():
             print(json.dumps({"profile_region": True, "steps": max(args.steps, 1), "stage_ms_per_step": {k: round(v, 4) for k, v in stage_ms.items()}}))
         batch.close()
         ctx.close()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             dist.destroy_process_group()
         return
@@ -257,12 +258,13 @@ def main():
         barrier()
         d3 = max_over_ranks(time.perf_counter() - t3)
         fails = [r["fail"] for r in recs]
-        c_true = -c3.Rw[-1].T @ c3.tw[-1]
+        last = [r for r in recs if "estimate_pos" in r][-1]  # the last iteration that produced a pose (a stationary tail publishes none)
+        c_true = -c3.Rw[last["frame"]].T @ c3.tw[last["frame"]]
         c3_out = {"value": round((n3 - 1) / d3, 2), "unit": "frames/s (one loop iteration of the node per frame)", "frames": n3, "size": "640x505",
                   "K": "config/rapallo_intrinsic.yaml via updateCameraMatrix", "ranks": world, "seconds": round(d3, 4),
                   "success": fails.count(3), "not_moving": fails.count(1), "fail_recover": fails.count(2), "fail_detection": fails.count(0),
                   "waves": stats.get("waves"), "gap_pairs": stats.get("gap_pairs"),
-                  "end_position_error_m": round(float(np.linalg.norm(recs[-1]["estimate_pos"] - c_true)), 3),
+                  "end_position_error_m": round(float(np.linalg.norm(last["estimate_pos"] - c_true)), 3),
                   "path_length_m": round(float(sum(c3.relative(k - 1, k)[2] for k in range(1, n3))), 2),
                   "note": "includes the per-chunk upload of the frames, result read-back, the gather of pair summaries and the host loop"}
         ctx3.close()
@@ -392,7 +394,7 @@ def main():
         print(json.dumps(line))
     batch.close()
     ctx.close()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -54,7 +54,7 @@ def gather_records(local: np.ndarray, n_pairs: int, rank: int, world: int, devic
     buf = torch.zeros((per, width), dtype=torch.float64, device=device)
     if len(local):
         buf[: len(local)] = torch.from_numpy(np.ascontiguousarray(local)).to(device)
-    if world > 1:
+    if world > 1 or (dist.is_available() and dist.is_initialized()):  # a one-rank group still goes through the collective
         parts = [torch.empty_like(buf) for _ in range(world)]
         dist.all_gather(parts, buf)
     else:
