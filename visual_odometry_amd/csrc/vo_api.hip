@@ -235,8 +235,6 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
     DetectTables t;
     vo_build_detect_tables(t, 0);
     int st = vo_upload_detect_tables(t);
-    if (st == VO_OK && (hipMalloc((void**)&ctx->d_redo_cnt, sizeof(int)) != hipSuccess || hipMemset(ctx->d_redo_cnt, 0, sizeof(int)) != hipSuccess))
-        st = VO_ERR_HIP;
     if (st == VO_OK) st = vo_build_window_tables(ctx);
     if (st == VO_OK) st = vo_geometry_init(ctx);
     if (st == VO_OK) st = vo_detect_init(ctx);
@@ -248,8 +246,7 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         vo_geometry_release(ctx);
         if (ctx->h_up) hipHostFree(ctx->h_up);
         if (ctx->h_down) hipHostFree(ctx->h_down);
-        if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
-        if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
+            if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
         if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
         hipEventDestroy(ctx->ev_fork);
         hipEventDestroy(ctx->ev_join);
@@ -276,7 +273,6 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     if (ctx->d_tmp) hipFree(ctx->d_tmp);
     if (ctx->h_up) hipHostFree(ctx->h_up);
     if (ctx->h_down) hipHostFree(ctx->h_down);
-    if (ctx->d_redo_cnt) hipFree(ctx->d_redo_cnt);
     if (ctx->d_win_cell) hipFree(ctx->d_win_cell);
     if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
     hipEventDestroy(ctx->ev_fork);
@@ -477,6 +473,8 @@ int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp)
     VO_TRY(dalloc(ps.cand_val, pk * 32));
     VO_TRY(dalloc(ps.cand_idx, pk * 32));
     VO_TRY(dalloc(ps.redo_list, pk));
+    VO_TRY(dalloc(ps.redo_cnt, 1));
+    VO_HIP(hipMemset(ps.redo_cnt, 0, sizeof(int)));
     VO_TRY(dalloc(ps.knn_idx, pk * 2));
     VO_TRY(dalloc(ps.knn_dist, pk * 2));
     VO_TRY(dalloc(ps.p1, pm * 2));
@@ -512,6 +510,7 @@ void vo_pairset_free(PairSet& ps) {
     dfree(ps.cand_val);
     dfree(ps.cand_idx);
     dfree(ps.redo_list);
+    dfree(ps.redo_cnt);
     dfree(ps.knn_idx);
     dfree(ps.knn_dist);
     dfree(ps.p1);
@@ -547,6 +546,7 @@ static int ctx_pairset(vo_ctx* ctx, int kp_cap, int match_cap) {
         kp_cap = std::max(kp_cap, ps.kp_cap);
         match_cap = std::max(match_cap, ps.match_cap);
     }
+    if (ctx->d_redo_cnt == ps.redo_cnt) ctx->d_redo_cnt = nullptr;  // about to be freed
     return vo_pairset_alloc(ps, 1, kp_cap, match_cap, kMaxHyp);
 }
 
@@ -602,7 +602,7 @@ extern "C" int vo_match_knn2(vo_ctx* ctx, const float* descA, int nA, const floa
     VO_TRY(bounce_up(ctx, up, 0, fs.cnt, c, sizeof(c)));
     VO_TRY(bounce_up(ctx, up, 64, fs.desc, descA, bA));
     VO_TRY(bounce_up(ctx, up, 64 + bA, fs.desc + (size_t)cap * 64, descB, bB));
-    VO_TRY(vo_enqueue_match(ctx, fs, ctx->ps, false));
+    VO_TRY(vo_enqueue_match(ctx, fs, ctx->ps, false, ctx->stream));
     BounceDown dn;
     VO_TRY(dn.begin(ctx, (size_t)nA * 2 * (sizeof(int) + sizeof(float))));
     VO_TRY(dn.add(idx2, ctx->ps.knn_idx, (size_t)nA * 2 * sizeof(int)));
@@ -626,7 +626,7 @@ extern "C" int vo_detect_match(vo_ctx* ctx, const uint8_t* img1, size_t step1, c
     VO_TRY(upload_frame(ctx, fs, 0, img1, step1));
     VO_TRY(upload_frame(ctx, fs, 1, img2, step2));
     VO_TRY(vo_enqueue_detect(ctx, fs, true));
-    VO_TRY(vo_enqueue_match(ctx, fs, ps, true));
+    VO_TRY(vo_enqueue_match(ctx, fs, ps, true, ctx->stream));
     // counters, pair state and the (capacity-sized) result arrays come down through the pinned bounce buffer in one go:
     // one synchronisation, then plain memcpys of the n_match entries the caller gets
     const size_t mc = (size_t)ps.match_cap;
@@ -882,7 +882,16 @@ static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq
     b->d_img[0] = b->fs.img;  // owned by the frame set
     bool ok = hipMalloc((void**)&b->d_img[1], fbytes + 256) == hipSuccess &&
               hipStreamCreateWithFlags(&b->stream_copy, hipStreamNonBlocking) == hipSuccess &&
-              hipEventCreateWithFlags(&b->ev_match, hipEventDisableTiming) == hipSuccess;
+              hipEventCreateWithFlags(&b->ev_detect, hipEventDisableTiming) == hipSuccess;
+    {  // second set of the feature buffers the matcher reads (FeatBuf): ~9.3 KB per keypoint slot
+        const FrameSet& fs = b->fs;
+        const size_t fc = (size_t)n_frames * fs.cap;
+        b->feat[0] = FeatBuf{fs.kp, fs.desc, fs.descT, fs.nrm, fs.nmax, fs.cnt};
+        FeatBuf& x = b->feat[1];
+        ok = ok && dalloc(x.kp, fc) == VO_OK && dalloc(x.desc, fc * 64) == VO_OK && dalloc(x.descT, fc * 72) == VO_OK &&
+             dalloc(x.nrm, fc) == VO_OK && dalloc(x.nmax, (size_t)n_frames) == VO_OK && dalloc(x.cnt, (size_t)n_frames) == VO_OK &&
+             hipMemset(x.cnt, 0, (size_t)n_frames * sizeof(FrameCounters)) == hipSuccess;
+    }
     for (int s = 0; s < 2 && ok; s++) {
         RunHost& rh = b->rh[s];
         ok = hipHostMalloc((void**)&b->h_stage[s], fbytes, hipHostMallocDefault) == hipSuccess &&
@@ -985,7 +994,16 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
     hipStreamSynchronize(b->ctx->stream);
     hipStreamSynchronize(b->ctx->stream_geo);
     if (b->stream_copy) hipStreamSynchronize(b->stream_copy);
+    if (b->ctx->d_redo_cnt == b->ps.redo_cnt) b->ctx->d_redo_cnt = nullptr;
     if (b->d_img[0]) b->fs.img = b->d_img[0];
+    if (b->feat[0].kp) {  // the frame set frees its own allocation, whichever set the latest run used
+        const FeatBuf& x = b->feat[0];
+        b->fs.kp = x.kp, b->fs.desc = x.desc, b->fs.descT = x.descT, b->fs.nrm = x.nrm, b->fs.nmax = x.nmax, b->fs.cnt = x.cnt;
+    }
+    {
+        FeatBuf& x = b->feat[1];
+        dfree(x.kp), dfree(x.desc), dfree(x.descT), dfree(x.nrm), dfree(x.nmax), dfree(x.cnt);
+    }
     vo_frameset_free(b->fs);
     vo_pairset_free(b->ps);
     if (b->d_img[1]) hipFree(b->d_img[1]);
@@ -1001,7 +1019,7 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
         if (rh.ev_state) hipEventDestroy(rh.ev_state);
         if (rh.ev_done) hipEventDestroy(rh.ev_done);
     }
-    if (b->ev_match) hipEventDestroy(b->ev_match);
+    if (b->ev_detect) hipEventDestroy(b->ev_detect);
     if (b->stream_copy) hipStreamDestroy(b->stream_copy);
     delete b;
 }
@@ -1066,33 +1084,41 @@ extern "C" int vo_batch_run(vo_batch* b) {
         b->fill_slot = 1;
     }
     b->fs.img = b->d_img[b->cur_slot];
+    {
+        // feature buffers of this run; the matcher of the run before the previous one read the same set (geometry stream)
+        const FeatBuf& x = b->feat[b->runs & 1];
+        b->fs.kp = x.kp, b->fs.desc = x.desc, b->fs.descT = x.descT, b->fs.nrm = x.nrm, b->fs.nmax = x.nmax, b->fs.cnt = x.cnt;
+        if (b->runs >= 2) VO_HIP(hipStreamWaitEvent(ctx->stream, rh.ev_done, 0));
+    }
     VO_TRY(reset_counters(ctx, b->fs));
     VO_TRY(vo_enqueue_detect(ctx, b->fs, true));
     VO_HIP(hipEventRecord(b->ev_img_free[b->cur_slot], ctx->stream));
     b->img_free_pending[b->cur_slot] = true;
-    // The geometry of the previous run may still be working on this batch's pair buffers on the geometry stream: detection
-    // and description (frame buffers only) have started already, everything that writes pair buffers waits for it.
-    if (b->runs > 0) VO_HIP(hipStreamWaitEvent(ctx->stream, b->rh[(b->runs - 1) & 1].ev_done, 0));
-    VO_HIP(hipMemcpyAsync(b->ps.frames, rh.frames, (size_t)b->n_pairs * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP(hipMemcpyAsync(b->ps.st, rh.init, (size_t)b->n_pairs * sizeof(PairState), hipMemcpyHostToDevice, ctx->stream));
-    VO_HIP(hipEventRecord(rh.ev_state, ctx->stream));
+    // Everything from the matcher on goes to the geometry stream, in order behind the previous run's geometry (which may still
+    // be working on this batch's pair buffers).  The main stream is free as soon as description is enqueued: the next run's
+    // detection (VALU-bound) then runs beside this run's matcher (MFMA- and gather-bound) and its RANSAC / pose / triangulation
+    // (a few single-wavefront kernels, ~1.6 ms of mostly idle GPU per step).
+    hipStream_t sg = ctx->stream_geo;
+    VO_HIP(hipEventRecord(b->ev_detect, ctx->stream));
+    VO_HIP(hipStreamWaitEvent(sg, b->ev_detect, 0));
+    VO_HIP(hipMemcpyAsync(b->ps.frames, rh.frames, (size_t)b->n_pairs * sizeof(int2), hipMemcpyHostToDevice, sg));
+    VO_HIP(hipMemcpyAsync(b->ps.st, rh.init, (size_t)b->n_pairs * sizeof(PairState), hipMemcpyHostToDevice, sg));
+    VO_HIP(hipEventRecord(rh.ev_state, sg));
     rh.state_pending = true;
-    VO_TRY(vo_enqueue_match(ctx, b->fs, b->ps, true));
-    VO_HIP(hipMemcpyAsync(rh.cnt, b->fs.cnt, (size_t)b->n_frames * sizeof(FrameCounters), hipMemcpyDeviceToHost, ctx->stream));
-    // RANSAC, pose and triangulation are a few single-wavefront kernels (~1.6 ms of mostly idle GPU per step): they go to the
-    // geometry stream, where they run under the detection of whatever the main stream does next
-    VO_HIP(hipEventRecord(b->ev_match, ctx->stream));
-    VO_HIP(hipStreamWaitEvent(ctx->stream_geo, b->ev_match, 0));
+    VO_TRY(vo_enqueue_match(ctx, b->fs, b->ps, true, sg));
+    VO_HIP(hipMemcpyAsync(rh.cnt, b->fs.cnt, (size_t)b->n_frames * sizeof(FrameCounters), hipMemcpyDeviceToHost, sg));
     GeoOptions o;
     o.prob = ctx->prm.ransac_prob;
     o.thr_px = ctx->prm.ransac_threshold;
     o.max_iters = ctx->prm.ransac_max_iters;
     o.seed = ctx->prm.ransac_seed;
     o.dist_thresh = ctx->prm.distance_threshold;
-    VO_TRY(vo_enqueue_geometry(ctx, b->ps, o, ctx->stream_geo));
+    VO_TRY(vo_enqueue_geometry(ctx, b->ps, o, sg));
     // the result records travel with the run: they are on the host when ev_done fires
-    VO_HIP(hipMemcpyAsync(rh.res, b->ps.st, (size_t)b->n_pairs * sizeof(PairState), hipMemcpyDeviceToHost, ctx->stream_geo));
-    VO_HIP(hipEventRecord(rh.ev_done, ctx->stream_geo));
+    VO_HIP(hipMemcpyAsync(rh.res, b->ps.st, (size_t)b->n_pairs * sizeof(PairState), hipMemcpyDeviceToHost, sg));
+    VO_HIP(hipEventRecord(rh.ev_done, sg));
+    // with the stage timers on every stage is measured alone: nothing of the next run starts before this one is over
+    if (ctx->profiling) VO_HIP(hipStreamWaitEvent(ctx->stream, rh.ev_done, 0));
     b->runs++;
     return VO_OK;
 }
@@ -1175,6 +1201,8 @@ extern "C" int vo_debug_fetch(vo_ctx* ctx, int what, void* dst, size_t bytes) {
         if (bytes < sizeof(int)) return VO_ERR_INVALID_ARG;
         VO_HIP(hipSetDevice(ctx->device));
         VO_HIP(hipStreamSynchronize(ctx->stream));
+        VO_HIP(hipStreamSynchronize(ctx->stream_geo));
+        if (!ctx->d_redo_cnt) return VO_ERR_INVALID_ARG;  // no matcher launch yet, or its batch is gone
         VO_HIP(hipMemcpy(dst, ctx->d_redo_cnt, sizeof(int), hipMemcpyDeviceToHost));
         return VO_OK;
     }

@@ -161,6 +161,7 @@ struct PairSet {
     int* cand_idx = nullptr;
     int* knn_idx = nullptr;     // [P][kp_cap][2]
     int* redo_list = nullptr;   // [P*kp_cap] queries whose shortlist could not be certified (pair*cap + q)
+    int* redo_cnt = nullptr;    // [1] length of redo_list (per pair set: matchers of two sets may run on two streams at once)
     float* knn_dist = nullptr;  // [P][kp_cap][2]
     float* p1 = nullptr;        // [P][match_cap][2]
     float* p2 = nullptr;
@@ -206,8 +207,7 @@ struct vo_ctx {
     int force_seq_describe = 0;     // vo_debug_set key 0
     int match_fp32 = 0;             // vo_debug_set key 2: shortlist on the FP32 MFMA (v_mfma_f32_32x32x2_f32) instead of split bf16
     int force_exact_match = 0;      // vo_debug_set key 1: no shortlist is certified, every query takes the exact scan
-    int* d_redo_cnt = nullptr;      // [1] length of the matcher's redo list; one per context: every launch of a context is
-                                    // on its one in-order stream (vo_debug_fetch 4 reads the last launch's value)
+    int* d_redo_cnt = nullptr;      // redo_cnt of the pair set of the latest matcher launch (not owned; vo_debug_fetch 4 reads it)
     StageTimer timers[ST_COUNT];
     // lazily sized scratch for the single-call entry points
     FrameSet fs;
@@ -222,6 +222,18 @@ struct vo_ctx {
     size_t h_down_bytes = 0;
 };
 
+// Feature buffers of a frame set that the matcher reads.  A batch owns two sets and alternates between them from run to run:
+// the matcher of run k works on the geometry stream while the main stream is already detecting run k + 1 into the other set
+// (the matcher is MFMA- and gather-bound, detection is VALU-bound: side by side they hide most of the matcher's time).
+struct FeatBuf {
+    vo_keypoint* kp = nullptr;
+    float* desc = nullptr;
+    float* descT = nullptr;
+    float* nrm = nullptr;
+    int* nmax = nullptr;
+    FrameCounters* cnt = nullptr;
+};
+
 // Host-side memory of one run of a batch, pinned: what the run uploads (a snapshot of the pairs' K / initial pose and of the
 // pair -> frame map, taken when vo_batch_run is called) and what it brings back.  A batch keeps two, used alternately, so
 // that the host can prepare and enqueue run k + 1 while run k is executing, and read run k's records while k + 1 runs.
@@ -230,8 +242,8 @@ struct RunHost {
     int2* frames = nullptr;        // [n_pairs]
     PairState* res = nullptr;      // [n_pairs] device state after the run
     FrameCounters* cnt = nullptr;  // [n_frames]
-    hipEvent_t ev_state = nullptr; // the upload of init / frames has finished (main stream)
-    hipEvent_t ev_done = nullptr;  // geometry finished and res / cnt are on the host (geometry stream)
+    hipEvent_t ev_state = nullptr; // the upload of init / frames has finished (geometry stream)
+    hipEvent_t ev_done = nullptr;  // matcher and geometry finished, res / cnt are on the host (geometry stream)
     bool state_pending = false;
 };
 
@@ -259,7 +271,8 @@ struct vo_batch {
     std::vector<uint8_t> staged;     // [n_frames]
     RunHost rh[2];
     int64_t runs = 0;                // runs enqueued so far; run k uses rh[k & 1]
-    hipEvent_t ev_match = nullptr;   // matcher of the latest run finished (main stream)
+    hipEvent_t ev_detect = nullptr;  // detection + description of the latest run finished (main stream)
+    FeatBuf feat[2];                 // run k detects into feat[k & 1]; feat[0] is the frame set's own allocation
 };
 
 // ---------------------------------------------------------------- helpers (vo_api.cpp)
@@ -289,7 +302,8 @@ int vo_enqueue_hessian_layer(vo_ctx* ctx, FrameSet& fs, int frame, int octave, i
 int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe);
 int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_det);
 // vo_match.hip
-int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter);
+// every launch goes to `stream` (the main stream for the single-call entry points, the geometry stream for a batch)
+int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter, hipStream_t stream);
 // vo_geometry.hip
 struct GeoOptions {
     bool run_ransac = true, run_pose = true, run_triang = true;

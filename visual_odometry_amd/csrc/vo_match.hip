@@ -647,14 +647,15 @@ __global__ __launch_bounds__(1024) void k_match_filter(const vo_keypoint* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
-int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
+int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter, hipStream_t stream) {
+    ctx->d_redo_cnt = ps.redo_cnt;
     const int cap = fs.cap, P = ps.P;
     {
-        StageScope sc(ctx, ST_MATCH_PREP);
-        VO_HIP(hipMemsetAsync(fs.nmax, 0, (size_t)fs.F * sizeof(int), ctx->stream));
-        VO_HIP(hipMemsetAsync(ctx->d_redo_cnt, 0, sizeof(int), ctx->stream));
+        StageScope sc(ctx, ST_MATCH_PREP, stream);
+        VO_HIP(hipMemsetAsync(fs.nmax, 0, (size_t)fs.F * sizeof(int), stream));
+        VO_HIP(hipMemsetAsync(ps.redo_cnt, 0, sizeof(int), stream));
         auto prep = ctx->match_fp32 ? k_match_prep<true> : k_match_prep<false>;
-        hipLaunchKernelGGL(prep, dim3(cap / 32, fs.F), dim3(64), 0, ctx->stream, fs.desc, fs.cnt, cap, reinterpret_cast<float4*>(fs.descT),
+        hipLaunchKernelGGL(prep, dim3(cap / 32, fs.F), dim3(64), 0, stream, fs.desc, fs.cnt, cap, reinterpret_cast<float4*>(fs.descT),
                            fs.nrm, fs.nmax);
         VO_HIP(hipGetLastError());
     }
@@ -663,24 +664,24 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter) {
     constexpr int kQueryBlocks = 2;
     const int ksplit = (P >= 8) ? 1 : 4;
     {
-        StageScope sc(ctx, ST_MATCH_MFMA);
+        StageScope sc(ctx, ST_MATCH_MFMA, stream);
         const int bpp = ((cap + 128 * kQueryBlocks - 1) / (128 * kQueryBlocks)) * ksplit;  // workgroups per pair: 4 query blocks of 64, one train split each
         auto shortlist = ctx->match_fp32 ? k_match_bf3<kQueryBlocks, true> : k_match_bf3<kQueryBlocks, false>;
-        hipLaunchKernelGGL(shortlist, dim3(bpp * P), dim3(256), 0, ctx->stream, fs.desc,
+        hipLaunchKernelGGL(shortlist, dim3(bpp * P), dim3(256), 0, stream, fs.desc,
                            reinterpret_cast<const uint4*>(fs.descT), fs.nrm, fs.cnt, cap, ps.frames, ksplit, bpp, (P % 8 == 0) ? 1 : 0,
                            ps.cand_val, ps.cand_idx);
         VO_HIP(hipGetLastError());
     }
     {
-        StageScope sc(ctx, ST_MATCH_SELECT);
+        StageScope sc(ctx, ST_MATCH_SELECT, stream);
         const float cert_scale = ctx->force_exact_match ? 1e30f : 1.f;
-        hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.cand_idx,
-                           ps.cand_val, fs.nmax, 2 * ksplit, cert_scale, ps.knn_idx, ps.knn_dist, ps.redo_list, ctx->d_redo_cnt);
-        hipLaunchKernelGGL(k_match_exact, dim3(1024), dim3(256), 0, ctx->stream, fs.desc, fs.cnt, cap, ps.frames, ps.redo_list,
-                           ctx->d_redo_cnt, ps.knn_idx, ps.knn_dist);
+        hipLaunchKernelGGL(k_match_select, dim3(cap / 8, P), dim3(256), 0, stream, fs.desc, fs.cnt, cap, ps.frames, ps.cand_idx,
+                           ps.cand_val, fs.nmax, 2 * ksplit, cert_scale, ps.knn_idx, ps.knn_dist, ps.redo_list, ps.redo_cnt);
+        hipLaunchKernelGGL(k_match_exact, dim3(1024), dim3(256), 0, stream, fs.desc, fs.cnt, cap, ps.frames, ps.redo_list,
+                           ps.redo_cnt, ps.knn_idx, ps.knn_dist);
         if (filter) {
             const vo_params& p = ctx->prm;
-            hipLaunchKernelGGL(k_match_filter, dim3(P), dim3(1024), 0, ctx->stream, fs.kp, fs.cnt, cap, ps.frames,
+            hipLaunchKernelGGL(k_match_filter, dim3(P), dim3(1024), 0, stream, fs.kp, fs.cnt, cap, ps.frames,
                                ps.knn_idx, ps.knn_dist, p.ratio_thresh, p.roi_x_lo, p.roi_y_lo, p.roi_x_hi, p.roi_y_hi, ps.match_cap,
                                ps.p1, ps.p2, ps.matches, ps.st);
         }
