@@ -1050,6 +1050,7 @@ __device__ __forceinline__ void wave_sync_lds() {  // LDS hand-off between lanes
 }
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
+typedef __attribute__((address_space(3))) uint32_t lds_u32;
 
 __device__ __forceinline__ int saturate_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
@@ -1720,7 +1721,19 @@ __global__ __launch_bounds__(256) void k_build_win_tables(CellTab* __restrict__ 
     __syncthreads();
     describe_pix_tab(tid, 256, win, scale, s_cell, s_pix);
     __syncthreads();
-    if (tid <= kPatch) g_cell[(size_t)win * (kPatch + 1) + tid] = s_cell[tid];
+    if (tid <= kPatch) {
+        // smallest and largest number of full-weight pixels of a cell of this window size: the bounds of the row pass's
+        // unmasked and masked groups (k_describe_tiled), the same in every lane
+        int nmin = 1 << 15, nmax = 0;
+        for (int c = 0; c <= kPatch; c++) {
+            const int n = s_cell[c].sx2 - s_cell[c].sx1;
+            nmin = min(nmin, n);
+            nmax = max(nmax, n);
+        }
+        CellTab ct = s_cell[tid];
+        ct.pad = nmin | (nmax << 16);
+        g_cell[(size_t)win * (kPatch + 1) + tid] = ct;
+    }
     for (int j = tid; j < win; j += 256) g_pix[(size_t)win * kWinTabPitch + j] = s_pix[j];
 }
 
@@ -1873,6 +1886,20 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         const int myrow = lane / (kPatch + 1), mycell = lane - myrow * (kPatch + 1);  // row pass: lane = (row mod 3, cell)
         CellTab myct = {};
         if (!area_fast) myct = s_cell[mycell];
+        // row pass (see there): the cell's byte stream starts at pixel sx1 - 1 = stream byte 0 (the head); bytes 1 .. n are the
+        // full-weight pixels.  Weights of stream bytes 0 .. 3 per lane; +0 where the byte is not part of the cell (x + 0 == x:
+        // every partial sum is >= +0)
+        // (windows above 128 px: every cell has at least five full-weight pixels, bytes 1 .. 3 always weigh a_mid)
+        constexpr bool kRpSmall = WHI <= kSmallWin;
+        const int rp_s0 = myct.sx1 - 1, rp_sx2 = myct.sx2;
+        const float rp_am = myct.a_mid;
+        const float rp_w0 = myct.has_head ? myct.a_head : 0.f, rp_wt = myct.has_tail ? myct.a_tail : 0.f;
+        float rp_w1 = rp_am, rp_w2 = rp_am, rp_w3 = rp_am;
+        if (kRpSmall) {
+            const int n = rp_sx2 - rp_s0 - 1;
+            rp_w1 = n >= 1 ? rp_am : 0.f, rp_w2 = n >= 2 ? rp_am : 0.f, rp_w3 = n >= 3 ? rp_am : 0.f;
+        }
+        const int rp_nmin = __builtin_amdgcn_readfirstlane(myct.pad) & 0xffff, rp_nmax = __builtin_amdgcn_readfirstlane(myct.pad) >> 16;
         // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane)
         float vacc = 0.f;
         int viacc = 0, dy = 0, left = iscale;
@@ -1932,7 +1959,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                 wave_sync_lds();
                 // INTER_AREA row pass: one (row, destination cell) per lane, the cell's pixels in table order
                 const int nrw = min(WR, win - wrow0);
-                const int nub = (int)scale + 1;
                 if (area_fast) {
                     for (int it = lane; it < nrw * (kPatch + 1); it += 64) {
                         const int rr = it / (kPatch + 1), cell = it - rr * (kPatch + 1);
@@ -1942,27 +1968,46 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                         s_rowi[(sidx * RS + wave * WR + rr) * (kPatch + 1) + cell] = tot;
                     }
                 } else if (lane < 3 * (kPatch + 1)) {
-                    // lane = (row mod 3, cell): the cell's table entry stays in registers for the whole keypoint
-                    const int n = myct.sx2 - myct.sx1;  // full-weight pixels of this cell: at most nub, the same bound in every lane
+                    // lane = (row mod 3, cell): the cell's table entry stays in registers for the whole keypoint.  The pixels a
+                    // cell reads are contiguous - head (sx1 - 1), full-weight pixels [sx1, sx2), tail (sx2) - so they come in
+                    // as a byte stream of ALIGNED words shifted into place (v_alignbyte): one LDS read per four pixels.  The
+                    // adds stay in pixel order; a pixel past a lane's own count is added with weight 0 or not at all.
                     for (int rr = myrow; rr < nrw; rr += 3) {
                         const lds_u8* p = wbase + rr * kPitch;
-                        const int ph = p[max(myct.sx1 - 1, 0)], pt = p[myct.sx2];
-                        const lds_u8* pm = p + myct.sx1;
-                        float acc = 0.f;
-                        if (myct.has_head) acc += (float)ph * myct.a_head;
-                        // four byte reads in flight per step; the adds stay in pixel order, lanes past their own count keep acc
-                        for (int k0 = 0; k0 < nub; k0 += 4) {
-                            const int v0 = pm[k0], v1 = pm[k0 + 1], v2 = pm[k0 + 2], v3 = pm[k0 + 3];
-                            const float a0 = acc + (float)v0 * myct.a_mid;
-                            acc = k0 < n ? a0 : acc;
-                            const float a1 = acc + (float)v1 * myct.a_mid;
-                            acc = k0 + 1 < n ? a1 : acc;
-                            const float a2 = acc + (float)v2 * myct.a_mid;
-                            acc = k0 + 2 < n ? a2 : acc;
-                            const float a3 = acc + (float)v3 * myct.a_mid;
-                            acc = k0 + 3 < n ? a3 : acc;
+                        const lds_u32* q = reinterpret_cast<const lds_u32*>(p + (rp_s0 & ~3));
+                        const uint32_t rp_sh = (uint32_t)rp_s0;  // v_alignbyte uses bits [1:0]
+                        const int rp_n = rp_sx2 - rp_s0 - 1;
+                        uint32_t lo = q[0], hi = q[1];
+                        const int pt = p[rp_sx2];
+                        uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
+                        float acc = (float)(w & 255u) * rp_w0;  // head, or +0
+                        acc += (float)((w >> 8) & 255u) * rp_w1;
+                        acc += (float)((w >> 16) & 255u) * rp_w2;
+                        acc += (float)(w >> 24) * rp_w3;
+                        int j = 4, qi = 2;
+                        for (; j + 3 <= rp_nmin; j += 4, qi++) {  // stream bytes j .. j + 3 are full-weight pixels in every lane
+                            lo = hi;
+                            hi = q[qi];
+                            w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
+                            acc += (float)(w & 255u) * rp_am;
+                            acc += (float)((w >> 8) & 255u) * rp_am;
+                            acc += (float)((w >> 16) & 255u) * rp_am;
+                            acc += (float)(w >> 24) * rp_am;
                         }
-                        if (myct.has_tail) acc += (float)pt * myct.a_tail;
+                        for (; j <= rp_nmax; j += 4, qi++) {  // lanes past their own count keep acc
+                            lo = hi;
+                            hi = q[qi];
+                            w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
+                            const float a0 = acc + (float)(w & 255u) * rp_am;
+                            acc = j <= rp_n ? a0 : acc;
+                            const float a1 = acc + (float)((w >> 8) & 255u) * rp_am;
+                            acc = j + 1 <= rp_n ? a1 : acc;
+                            const float a2 = acc + (float)((w >> 16) & 255u) * rp_am;
+                            acc = j + 2 <= rp_n ? a2 : acc;
+                            const float a3 = acc + (float)(w >> 24) * rp_am;
+                            acc = j + 3 <= rp_n ? a3 : acc;
+                        }
+                        acc += (float)pt * rp_wt;  // tail, or +0
                         s_rowv[(sidx * RS + wave * WR + rr) * (kPatch + 1) + mycell] = acc;
                     }
                 }
