@@ -1051,6 +1051,7 @@ __device__ __forceinline__ void wave_sync_lds() {  // LDS hand-off between lanes
 
 typedef __attribute__((address_space(3))) uint8_t lds_u8;
 typedef __attribute__((address_space(3))) uint32_t lds_u32;
+typedef __attribute__((address_space(3))) float lds_f32;
 
 __device__ __forceinline__ int saturate_u8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
@@ -1972,8 +1973,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                     // cell reads are contiguous - head (sx1 - 1), full-weight pixels [sx1, sx2), tail (sx2) - so they come in
                     // as a byte stream of ALIGNED words shifted into place (v_alignbyte): one LDS read per four pixels.  The
                     // adds stay in pixel order; a pixel past a lane's own count is added with weight 0 or not at all.
-                    for (int rr = myrow; rr < nrw; rr += 3) {
-                        const lds_u8* p = wbase + rr * kPitch;
+                    // (running LDS pointers: an index product per row compiles to a quarter-rate 64-bit multiply-add)
+                    const lds_u8* p = wbase + myrow * kPitch;
+                    lds_f32* outp = (lds_f32*)s_rowv + ((sidx * RS + wave * WR + myrow) * (kPatch + 1) + mycell);
+                    for (int rr = myrow; rr < nrw; rr += 3, p += 3 * kPitch, outp += 3 * (kPatch + 1)) {
                         const lds_u32* q = reinterpret_cast<const lds_u32*>(p + (rp_s0 & ~3));
                         const uint32_t rp_sh = (uint32_t)rp_s0;  // v_alignbyte uses bits [1:0]
                         const int rp_n = rp_sx2 - rp_s0 - 1;
@@ -2008,7 +2011,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                             acc = j + 3 <= rp_n ? a3 : acc;
                         }
                         acc += (float)pt * rp_wt;  // tail, or +0
-                        s_rowv[(sidx * RS + wave * WR + rr) * (kPatch + 1) + mycell] = acc;
+                        *outp = acc;
                     }
                 }
             }
@@ -2038,14 +2041,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                     }
                 } else {
                     // eight rows at a time: their table entries and row sums are read together, the adds stay in row order
-                    for (int q0 = 0; q0 < nrows; q0 += 8) {
+                    const lds_f32* vrow = (const lds_f32*)s_rowv + ob;
+                    const int ilast = (nrows - 1) * (kPatch + 1);
+                    for (int q0 = 0, i8 = 0; q0 < nrows; q0 += 8, i8 += 8 * (kPatch + 1)) {
                         PixTab t[8];
                         float val[8];
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
                             const int q = min(q0 + u, nrows - 1);
                             t[u] = pix_win[i0 + q];
-                            val[u] = s_rowv[ob + q * (kPatch + 1)];
+                            val[u] = vrow[min(i8 + u * (kPatch + 1), ilast)];
                         }
 #pragma unroll
                         for (int u = 0; u < 8; u++) {
