@@ -376,7 +376,7 @@ def main():
                        "mean_keypoints_per_frame": round(kp, 1), "mean_matches": round(float(rec_all[:, 3].mean()), 1),
                        "mean_inliers": round(float(rec_all[:, 4].mean()), 1), "mean_ransac_iterations": round(float(rec_all[:, 8].mean()), 1),
                        "pairs_with_pose": int(rec_all[:, 7].sum()), "pairs_total": int(len(rec_all)),
-                       "parallelism": f"pairs sharded over {world} rank(s), one GPU each, no data-path collective; result records all-gathered ({backend})",
+                       "parallelism": f"pairs sharded over {world} rank(s) on {min(world, max(ndev, 1)) if backend != 'nccl' else world} GPU(s), no data-path collective; result records all-gathered ({backend})",
                        "input_generation_s": round(gen_s, 1), "input_generation_workers": gen_workers},
             "resident": {"value": round(pairs / dt_res, 2), "unit": "frame-pairs/s", "ms_per_step": round(dt_res / args.steps * 1e3, 4),
                          "note": "same batch re-run with the frames already in HBM (no upload): what `value` would be without PCIe"},
