@@ -229,20 +229,33 @@ __global__ __launch_bounds__(256) void k_colsum(const uint8_t* __restrict__ img,
     colsum[((size_t)frame * nbands + band) * W + x] = s;
 }
 
-// four columns per lane from aligned words (W and the frame pitch multiples of four)
+// four columns per lane from aligned words (W and the frame pitch multiples of four); the grid is flat over (band, column
+// quad) so that no lane idles at a row's end, and a full band's 16 loads go out back to back
 __global__ __launch_bounds__(256) void k_colsum4(const uint8_t* __restrict__ img, size_t img_stride, int H, int W,
                                                  int nbands, int32_t* __restrict__ colsum) {
-    const int frame = blockIdx.z, band = blockIdx.y;
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 4;
-    if (x >= W) return;
+    const int frame = blockIdx.z, wq = W >> 2;
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nbands * wq) return;
+    const int band = idx / wq, x = (idx - band * wq) * 4;
     const uint8_t* p = img + (size_t)frame * img_stride + (size_t)band * kBand * W + x;
     const int rows = min(kBand, H - band * kBand);
     // two columns per accumulator: 16 rows x 255 fit 16 bits
     uint32_t even = 0, odd = 0;
-    for (int r = 0; r < rows; r++) {
-        const uint32_t v = *reinterpret_cast<const uint32_t*>(p + (size_t)r * W);
-        even += v & 0x00ff00ffu;
-        odd += (v >> 8) & 0x00ff00ffu;
+    if (rows == kBand) {
+        uint32_t v[kBand];
+#pragma unroll
+        for (int r = 0; r < kBand; r++) v[r] = *reinterpret_cast<const uint32_t*>(p + (size_t)r * W);
+#pragma unroll
+        for (int r = 0; r < kBand; r++) {
+            even += v[r] & 0x00ff00ffu;
+            odd += (v[r] >> 8) & 0x00ff00ffu;
+        }
+    } else {
+        for (int r = 0; r < rows; r++) {
+            const uint32_t v = *reinterpret_cast<const uint32_t*>(p + (size_t)r * W);
+            even += v & 0x00ff00ffu;
+            odd += (v >> 8) & 0x00ff00ffu;
+        }
     }
     const int4 o = make_int4((int)(even & 0xffffu), (int)(odd & 0xffffu), (int)(even >> 16), (int)(odd >> 16));
     *reinterpret_cast<int4*>(colsum + ((size_t)frame * nbands + band) * W + x) = o;
@@ -255,7 +268,18 @@ __global__ __launch_bounds__(256) void k_colsum_scan(int W, int nbands, int32_t*
     if (x >= W) return;
     int32_t* p = colsum + (size_t)frame * nbands * W + x;
     int32_t run = 0;
-    for (int b = 0; b < nbands; b++) {
+    int b = 0;
+    for (; b + 8 <= nbands; b += 8) {  // eight loads in flight
+        int32_t v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = p[(size_t)(b + u) * W];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            p[(size_t)(b + u) * W] = run;
+            run += v[u];
+        }
+    }
+    for (; b < nbands; b++) {
         const int32_t v = p[(size_t)b * W];
         p[(size_t)b * W] = run;
         run += v;
@@ -431,7 +455,7 @@ int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs) {
     dim3 g1((fs.W + 255) / 256, nbands, fs.F);
     const bool aligned4 = fs.W % 4 == 0 && fs.img_stride() % 4 == 0;
     if (aligned4)
-        hipLaunchKernelGGL(k_colsum4, dim3((fs.W / 4 + 255) / 256, nbands, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+        hipLaunchKernelGGL(k_colsum4, dim3((nbands * (fs.W / 4) + 255) / 256, 1, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                            fs.H, fs.W, nbands, fs.colsum);
     else
         hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
