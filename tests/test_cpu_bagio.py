@@ -124,6 +124,12 @@ def test_image_decoding_and_directory_source(tmp_path):
     jpg = bagio.decode_image({"header": {}, "format": "jpeg", "data": b.getvalue()}, "sensor_msgs/CompressedImage")
     assert jpg.shape == img.shape and np.abs(jpg.astype(int) - img).mean() < 6  # lossy, but blue stays channel 0
     assert jpg[5, 5, 0] > 150 and jpg[20, 20, 2] > 130 and jpg[20, 20, 1] < 60
+    rng = np.random.default_rng(4)
+    noise = rng.integers(0, 256, (40, 50, 3), dtype=np.uint8)  # PNG payloads are lossless: every byte comes back, as BGR
+    b = io.BytesIO()
+    Image.fromarray(noise[..., ::-1]).save(b, "PNG")
+    png = bagio.decode_image({"header": {}, "format": "png", "data": b.getvalue()}, "sensor_msgs/CompressedImage")
+    assert np.array_equal(png, noise)
     raw = {"height": 40, "width": 50, "encoding": "rgb8", "is_bigendian": 0, "step": 152, "data": np.pad(img[..., ::-1].reshape(40, 150), ((0, 0), (0, 2))).tobytes()}
     assert np.array_equal(bagio.decode_image(raw, "sensor_msgs/Image"), img)
     mono = {"height": 40, "width": 50, "encoding": "mono8", "is_bigendian": 0, "step": 50, "data": img[..., 0].tobytes()}
