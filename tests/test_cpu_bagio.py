@@ -85,6 +85,9 @@ def test_bag_round_trip_and_sequence_reader(tmp_path, compression):
     assert np.allclose(stamps, 100 + 0.1 * np.arange(7)) and np.allclose(alts, [2, 3, 4, 4, 6, 7, 8])
     f2, s2, _ = bagio.read_sequence(path, max_frames=3, use_header_stamp=False)
     assert len(f2) == 3 and np.allclose(s2, 100 + 0.1 * np.arange(3) + 0.003)
+    # payloads decoded on host threads: the same frames in the same order
+    f3, s3, a3 = bagio.read_sequence(path, decode_workers=3)
+    assert len(f3) == 7 and all(np.array_equal(a, b) for a, b in zip(f3, imgs)) and np.array_equal(s3, stamps) and np.array_equal(a3, alts)
 
 
 def test_hand_assembled_records():

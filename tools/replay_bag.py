@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--max-frames", type=int, default=None)
     ap.add_argument("--motion2d", action="store_true")
     ap.add_argument("--chunk", type=int, default=64)
+    ap.add_argument("--decode-workers", type=int, default=min(16, len(os.sched_getaffinity(0))), help="host threads decoding JPEG / PNG payloads")
     a = ap.parse_args()
 
     from visual_odometry_amd import bagio, chain, replay
@@ -41,7 +42,7 @@ def main():
         alts = np.full(len(frames), a.altitude if a.altitude is not None else 1.0)
     else:
         frames, stamps, alts = bagio.read_sequence(a.source, a.image_topic, a.altitude_topic, max_frames=a.max_frames,
-                                                     relative_stamps=True)  # exact dt from the integer (sec, nsec) stamps
+                                                     relative_stamps=True, decode_workers=a.decode_workers)  # exact dt from the integer (sec, nsec) stamps
         if a.altitude is not None:
             alts = np.full(len(frames), a.altitude)
     if len(frames) < 2:

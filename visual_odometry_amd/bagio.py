@@ -542,22 +542,34 @@ def decode_image(msg: dict, msg_type: str) -> np.ndarray:
 
 
 def read_sequence(path, image_topic="/pylon_camera/image_raw/compressed", altitude_topic="/drivers/altitude", altitude_field="altitude",
-                  max_frames=None, use_header_stamp=True, relative_stamps=False):
+                  max_frames=None, use_header_stamp=True, relative_stamps=False, decode_workers=1):
     """Frames, stamps [s] and the latest altitude at each frame, in bag order - the node's view of its topics
-    (it keeps the latest message of every topic, src/visual_Odometry.cpp:112-177)."""
+    (it keeps the latest message of every topic, src/visual_Odometry.cpp:112-177).  decode_workers > 1 decodes the image
+    payloads on that many host threads (Pillow releases the interpreter lock while it decodes: a 2560 x 2056 JPEG costs
+    ~15 ms of one core, the front end takes a frame in well under a millisecond); the result is the same list, in order."""
     bag = BagReader(path)
     frames, stamps, alts = [], [], []
     last_alt = float("nan")
+    pool = None
+    if decode_workers > 1:
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = ThreadPoolExecutor(decode_workers)
     for topic, conn, t, raw in bag.messages([image_topic, altitude_topic]):
         msg = conn.codec.decode(raw)
         if topic == altitude_topic:
             last_alt = float(msg[altitude_field])
             continue
-        frames.append(decode_image(msg, conn.type))
+        frames.append(pool.submit(decode_image, msg, conn.type) if pool else decode_image(msg, conn.type))
         stamps.append(msg["header"]["stamp"] if use_header_stamp and "header" in msg else t)
         alts.append(last_alt)
         if max_frames is not None and len(frames) >= max_frames:
             break
+    if pool:
+        try:
+            frames = [f.result() for f in frames]
+        finally:
+            pool.shutdown()
     if relative_stamps:
         # seconds since the first frame, from the integer (sec, nsec) pairs: exact differences (the float form of an epoch
         # stamp resolves only ~0.2 us), which is what the replay's dt needs
