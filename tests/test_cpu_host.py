@@ -138,3 +138,33 @@ def test_matcher_device_code_has_no_mfma_read_hazard():
     import subprocess
 
     assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazard.py")]) == 0
+
+
+def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
+    """`python bench.py --gpus N` outside torchrun: N ranks are started as CHILD processes through torch.distributed.run on
+    127.0.0.1 (this process has not imported torch or touched HIP at that point), with the caller's arguments passed on."""
+    import importlib
+    import subprocess
+    import sys
+
+    sys.path.insert(0, ROOT)
+    bench = importlib.import_module("bench")
+    seen = {}
+
+    def fake_call(cmd, env=None):
+        seen["cmd"], seen["env"] = cmd, env
+        return 7
+
+    monkeypatch.setattr(subprocess, "call", fake_call)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
+    monkeypatch.delenv("RANK", raising=False)
+    torch_loaded_before = "torch" in sys.modules
+    with pytest.raises(SystemExit) as e:
+        bench.main()
+    assert e.value.code == 7  # the children's exit code is this process's
+    cmd = seen["cmd"]
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"] and "--nnodes=1" in cmd and "--nproc-per-node=4" in cmd
+    assert cmd[cmd.index("--master-addr") + 1] == "127.0.0.1" and int(cmd[cmd.index("--master-port") + 1]) > 0
+    assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert ("torch" in sys.modules) == torch_loaded_before  # launching did not pull torch into the parent
