@@ -223,9 +223,18 @@ int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out);
 /* the same for the latest run (age 0) or the run before it (age 1): a pipelined caller enqueues run k + 1 and then reads
  * run k's records while k + 1 executes.  The records of a run stay valid until the second run after it is enqueued.    */
 int vo_batch_get_run(vo_batch* b, int age, int pair, vo_pair_out* out);
+/* the records of all n_pairs pairs of that run in one call (outs[n_pairs]; same waiting rule)                            */
+int vo_batch_get_run_all(vo_batch* b, int age, vo_pair_out* outs);
 /* optional bulk outputs of a pair of the LATEST run (any pointer may be NULL); waits for that run                      */
 int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask,
                         int cap, double* Xk, int cap_world);
+/* The same for EVERY pair of the latest run in one download (one synchronisation instead of one per pair; the offline replay
+ * reads all pairs of a chunk).  Row p of an output belongs to pair p: p1xy / p2xy [n_pairs][cap][2], m and mask
+ * [n_pairs][cap], Xk [n_pairs][3][cap_world]; only the first n_match (n_world) entries of a row are written with results.
+ * Null outputs are skipped.  VO_ERR_CAPACITY when some pair holds more than cap matches (cap_world world points).
+ * Replaces the per-pair reads of KpAsPoint2f_Match / world_points after camera_utility.hpp:795-808, 343-350. */
+int vo_batch_get_points_all(vo_batch* b, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask, int cap, double* Xk,
+                            int cap_world);
 
 /* Sequence batch (offline replay of consecutive frames; no counterpart in the reference, which re-detects prev_img
  * in every iteration, src/visual_Odometry.cpp:296): n_frames frames are detected and described once each;
@@ -273,6 +282,11 @@ int vo_abs_diff3(const double a[3], const double b[3], int is_angle, double out[
 /* estimateTwist / computeAngularVel, math_utility.hpp:312-357                                                    */
 int vo_estimate_twist(double dt, const double R[9], const double t[3], double sf, const double rpy[3], const double Rbc[9],
                       int motion2d, double lin[3], double ang[3]);
+/* One pose update of the replayed loop in one call: absolutePose on the running pose (src/visual_Odometry.cpp:402-410), then
+ * publish_VOResults' rpy = mat2Euler(orientation * Rbc^T) and twist (:553-570; zero when dt == 0).  Xk / Xw as above.   */
+int vo_loop_pose_update(double orientation_io[9], double location_io[3], const double R[9], const double t[3], double sf,
+                        const double* Xk, int n, double* Xw, double dt, const double Rbc[9], int motion2d, double rpy[3],
+                        double lin[3], double ang[3]);
 
 /* ---- N2: get_image, camera_utility.hpp:147-179 -- the per-frame preprocessing of the node -----------
  * resize(INTER_AREA) :119-136 -> undistort(K, dist) :155 -> cvtColor(COLOR_RGB2GRAY) on the node's BGR frames :160 ->

@@ -109,3 +109,35 @@ def test_estimate_twist_2d_and_3d():
          -np.cos(rpy[0]) * d[1] + np.sin(rpy[0]) * d[2]]
     np.testing.assert_allclose(ang3, w, atol=1e-13)
     assert np.array_equal(lin3, lin)
+
+
+def test_loop_pose_update_equals_the_three_calls():
+    """vo_loop_pose_update = absolutePose + mat2Euler(orientation Rbc^T) + estimateTwist, bit for bit (the replay calls it
+    once per frame instead of the three)."""
+    rng = np.random.default_rng(9)
+
+    def rot(v):
+        th = np.linalg.norm(v)
+        k = v / th
+        Kx = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * Kx + (1 - np.cos(th)) * Kx @ Kx
+
+    for trial in range(20):
+        orientation, location = rot(rng.normal(size=3)), rng.normal(size=3) * 5
+        R, t, Rbc = rot(rng.normal(size=3) * 0.05), rng.normal(size=3), rot(rng.normal(size=3))
+        t /= np.linalg.norm(t)
+        SF, dt = float(rng.uniform(0.1, 3)), (0.0 if trial == 7 else float(rng.uniform(0.05, 0.5)))
+        X = rng.normal(size=(3, 11)) if trial % 2 else None
+        if X is not None:
+            loc_w, ori_w, Xw_w = chain.absolutePose(orientation, location, R, t, SF, X)
+        else:
+            loc_w, ori_w = chain.absolutePose(orientation, location, R, t, SF)
+            Xw_w = None
+        M = np.array([[sum(ori_w[i, k] * Rbc[j, k] for k in range(3)) for j in range(3)] for i in range(3)])  # the library's order of adds
+        rpy_w = chain.mat2Euler(M)
+        lin_w, ang_w = chain.estimateTwist(dt, R, t, SF, rpy_w, Rbc, False) if dt != 0 else (np.zeros(3), np.zeros(3))
+        o, l = np.ascontiguousarray(orientation.copy()), location.copy()
+        rpy, lin, ang, Xw = chain.loopPoseUpdate(o, l, R, t, SF, dt, Rbc, False, X)
+        assert np.array_equal(o, ori_w) and np.array_equal(l, loc_w)
+        assert np.array_equal(rpy, rpy_w) and np.array_equal(lin, lin_w) and np.array_equal(ang, ang_w)
+        assert (Xw is None) == (Xw_w is None) and (Xw is None or np.array_equal(Xw, Xw_w))

@@ -103,6 +103,25 @@ def estimateTwist(deltaT: float, R, t, SF: float, estimate_rpy, Rbc, motion2D: b
     return lin, ang
 
 
+def loopPoseUpdate(orientation, location, R, t, SF: float, dt: float, Rbc, motion2D: bool, world_points=None):
+    """absolutePose + mat2Euler(orientation Rbc^T) + estimateTwist in one library call (vo_loop_pose_update).
+    orientation (3,3) and location (3,) must be C-contiguous float64 arrays; they are updated IN PLACE.
+    Returns (rpy, twist_linear, twist_angular, world_pointsW or None)."""
+    R, t, Rbc = _d(R, (3, 3)), _d(t, (3,)), _d(Rbc, (3, 3))
+    rpy, lin, ang = np.zeros(3), np.zeros(3), np.zeros(3)
+    X = Xw = None
+    n = 0
+    if world_points is not None:
+        X = _d(world_points)
+        n = X.shape[1]
+        Xw = np.zeros_like(X)
+    _chk(_L().vo_loop_pose_update(orientation.ctypes.data_as(_f64p), location.ctypes.data_as(_f64p), R.ctypes.data_as(_f64p),
+                                  t.ctypes.data_as(_f64p), C.c_double(SF), X.ctypes.data_as(_f64p) if X is not None else None, n,
+                                  Xw.ctypes.data_as(_f64p) if Xw is not None else None, C.c_double(dt), Rbc.ctypes.data_as(_f64p),
+                                  int(motion2D), rpy.ctypes.data_as(_f64p), lin.ctypes.data_as(_f64p), ang.ctypes.data_as(_f64p)))
+    return rpy, lin, ang, Xw
+
+
 def gate(p1, p2):
     """The gate sequence of the node's main loop (visual_Odometry.cpp:303-326): returns None when the pair goes on to
     optRelativePose, else the fail_V0 code the node would publish."""

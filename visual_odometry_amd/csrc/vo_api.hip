@@ -1020,6 +1020,7 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
         if (rh.ev_done) hipEventDestroy(rh.ev_done);
     }
     if (b->ev_detect) hipEventDestroy(b->ev_detect);
+    if (b->h_bulk) hipHostFree(b->h_bulk);
     if (b->stream_copy) hipStreamDestroy(b->stream_copy);
     delete b;
 }
@@ -1166,6 +1167,12 @@ extern "C" int vo_batch_get_run(vo_batch* b, int age, int pair, vo_pair_out* out
 
 extern "C" int vo_batch_get(vo_batch* b, int pair, vo_pair_out* out) { return vo_batch_get_run(b, 0, pair, out); }
 
+extern "C" int vo_batch_get_run_all(vo_batch* b, int age, vo_pair_out* outs) {
+    if (!b || !outs) return VO_ERR_INVALID_ARG;
+    for (int p = 0; p < b->n_pairs; p++) VO_TRY(vo_batch_get_run(b, age, p, outs + p));
+    return VO_OK;
+}
+
 extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask, int cap,
                                    double* Xk, int cap_world) {
     if (!b || pair < 0 || pair >= b->n_pairs || cap < 0 || cap_world < 0) return VO_ERR_INVALID_ARG;
@@ -1190,6 +1197,63 @@ extern "C" int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2
     if (Xk && S.n_world > 0)
         for (int r = 0; r < 3; r++) VO_TRY(dn.add(Xk + (size_t)r * cap_world, ps.Xk + (pair * 3 + r) * mc, wb));
     return dn.finish();
+}
+
+// Points of EVERY pair of the latest run in one download: strided device -> pinned copies on the batch's COPY stream (the main
+// stream may already be busy with another batch of the context), one wait, one pass of host memcpys.
+extern "C" int vo_batch_get_points_all(vo_batch* b, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask, int cap, double* Xk,
+                                       int cap_world) {
+    if (!b || cap < 0 || cap_world < 0) return VO_ERR_INVALID_ARG;
+    vo_ctx* ctx = b->ctx;
+    VO_HIP(hipSetDevice(ctx->device));
+    RunHost* rh = nullptr;
+    VO_TRY(run_records(b, 0, &rh));
+    const PairSet& ps = b->ps;
+    const size_t mc = ps.match_cap, P = (size_t)b->n_pairs;
+    for (size_t p = 0; p < P; p++) {
+        const PairState& S = rh->res[p];
+        if (std::min(S.n_used, (int)mc) > cap || (Xk && S.n_world > cap_world)) return VO_ERR_CAPACITY;
+    }
+    const size_t w = std::min((size_t)cap, mc), ww = std::min((size_t)cap_world, mc);
+    struct Part {
+        void* dst;
+        const void* src;
+        size_t elem, width, rows, dst_width;
+    };
+    const Part parts[5] = {{p1xy, ps.p1, 2 * sizeof(float), w, P, (size_t)cap},   {p2xy, ps.p2, 2 * sizeof(float), w, P, (size_t)cap},
+                           {m, ps.matches, sizeof(vo_dmatch), w, P, (size_t)cap}, {mask, ps.mask, 1, w, P, (size_t)cap},
+                           {Xk, ps.Xk, sizeof(double), ww, 3 * P, (size_t)cap_world}};
+    size_t total = 0;
+    for (const Part& q : parts)
+        if (q.dst && q.width) total += (q.elem * q.width * q.rows + 255) & ~(size_t)255;
+    if (!total) return VO_OK;
+    if (total > b->h_bulk_bytes) {  // the batch's own pinned buffer: nothing of this batch is in flight after run_records
+        if (b->h_bulk) hipHostFree(b->h_bulk);
+        b->h_bulk = nullptr;
+        b->h_bulk_bytes = 0;
+        const size_t nb = (total + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+        VO_HIP(hipHostMalloc((void**)&b->h_bulk, nb, hipHostMallocDefault));
+        b->h_bulk_bytes = nb;
+    }
+    size_t off = 0;
+    for (const Part& q : parts) {
+        if (!q.dst || !q.width) continue;
+        VO_HIP(hipMemcpy2DAsync(b->h_bulk + off, q.elem * q.width, q.src, q.elem * mc, q.elem * q.width, q.rows, hipMemcpyDeviceToHost,
+                                b->stream_copy));
+        off += (q.elem * q.width * q.rows + 255) & ~(size_t)255;
+    }
+    VO_HIP(hipStreamSynchronize(b->stream_copy));
+    off = 0;
+    for (const Part& q : parts) {
+        if (!q.dst || !q.width) continue;
+        const size_t rb = q.elem * q.width;
+        if (q.width == q.dst_width)
+            std::memcpy(q.dst, b->h_bulk + off, rb * q.rows);
+        else
+            for (size_t r = 0; r < q.rows; r++) std::memcpy((uint8_t*)q.dst + r * q.elem * q.dst_width, b->h_bulk + off + r * rb, rb);
+        off += (rb * q.rows + 255) & ~(size_t)255;
+    }
+    return VO_OK;
 }
 
 // ---------------------------------------------------------------- inspection of the last single-call RANSAC

@@ -126,3 +126,24 @@ extern "C" int vo_estimate_twist(double dt, const double R[9], const double t[3]
     }
     return VO_OK;
 }
+
+// One pose update of the node's loop as the offline replay performs it, in one call: absolutePose on the running pose
+// (src/visual_Odometry.cpp:402-410 -> camera_utility.hpp:414-501), then what publish_VOResults derives from it (:553-570):
+// rpy = mat2Euler(orientation * Rbc^T) and the twist (zero when dt == 0).  The same arithmetic as the three separate calls.
+extern "C" int vo_loop_pose_update(double orientation_io[9], double location_io[3], const double R[9], const double t[3], double sf,
+                                   const double* Xk, int n, double* Xw, double dt, const double Rbc[9], int motion2d, double rpy[3],
+                                   double lin[3], double ang[3]) {
+    if (!orientation_io || !location_io || !R || !t || !Rbc || !rpy || !lin || !ang) return VO_ERR_INVALID_ARG;
+    double t_wk[3], R_wk[9];
+    const int st = vo_absolute_pose(orientation_io, location_io, R, t, sf, Xk, n, t_wk, R_wk, Xw);
+    if (st != VO_OK) return st;
+    for (int i = 0; i < 3; i++) location_io[i] = t_wk[i];
+    for (int i = 0; i < 9; i++) orientation_io[i] = R_wk[i];
+    double M[9];
+    mat3_mul_bt(orientation_io, Rbc, M);
+    vo_mat2euler(M, rpy);
+    if (dt != 0)
+        return vo_estimate_twist(dt, R, t, sf, rpy, Rbc, motion2d, lin, ang);
+    for (int i = 0; i < 3; i++) lin[i] = ang[i] = 0;
+    return VO_OK;
+}

@@ -273,6 +273,8 @@ struct vo_batch {
     int64_t runs = 0;                // runs enqueued so far; run k uses rh[k & 1]
     hipEvent_t ev_detect = nullptr;  // detection + description of the latest run finished (main stream)
     FeatBuf feat[2];                 // run k detects into feat[k & 1]; feat[0] is the frame set's own allocation
+    uint8_t* h_bulk = nullptr;       // pinned landing buffer of vo_batch_get_points_all, grown on demand
+    size_t h_bulk_bytes = 0;
 };
 
 // ---------------------------------------------------------------- helpers (vo_api.cpp)

@@ -72,7 +72,23 @@ class Context:
         if st != 0:
             raise VoError(st, self.lib)
 
+    def cached_batch(self, key, make):
+        """A batch that lives as long as the context (the replay reuses its sequence / pair batches from call to call:
+        creating and destroying one costs ~4 ms each, hipFree synchronises the device)."""
+        cache = self.__dict__.setdefault("_batch_cache", {})
+        if key in cache:
+            cache[key] = cache.pop(key)  # most recently used last
+            return cache[key]
+        same = [k for k in cache if k[0] == key[0]]
+        for k in same[: max(0, len(same) - 5)]:  # at most six batches of a kind stay alive (the replay uses two at a time)
+            cache.pop(k).close()
+        cache[key] = make()
+        return cache[key]
+
     def close(self):
+        for b in list(self.__dict__.get("_batch_cache", {}).values()):
+            b.close()
+        self.__dict__.get("_batch_cache", {}).clear()
         if self._h:
             self.lib.vo_ctx_destroy.argtypes = [C.c_void_p]
             self.lib.vo_ctx_destroy(self._h)
@@ -344,6 +360,29 @@ class Batch:
         o = self.get(i)
         nm = max(o.n_match, 0)
         return p1[:nm], p2[:nm], m[:nm], mask[:nm], X[:, : max(o.n_world, 0)]
+
+
+    def get_all(self):
+        """(records, points) of EVERY pair of the latest run: one wait and one download (vo_batch_get_points_all).  points[i] =
+        (p1, p2, matches, mask, Xk) as get_points(i) returns them - views into shared arrays."""
+        outs = (VoPairOut * self.n_pairs)()
+        self.ctx._chk(self.ctx.lib.vo_batch_get_run_all(self._h, 0, outs))
+        outs = list(outs)
+        cap = max(1, max(o.n_match for o in outs))
+        capw = max(1, max(o.n_world for o in outs))
+        P = self.n_pairs
+        p1 = np.zeros((P, cap, 2), np.float32)
+        p2 = np.zeros((P, cap, 2), np.float32)
+        m = np.zeros((P, cap), DM_DTYPE)
+        mask = np.zeros((P, cap), np.uint8)
+        X = np.zeros((P, 3, capw), np.float64)
+        self.ctx._chk(self.ctx.lib.vo_batch_get_points_all(self._h, _p(p1, f32p), _p(p2, f32p), m.ctypes.data_as(C.c_void_p), _p(mask, u8p), cap,
+                                                           _p(X, f64p), capw))
+        pts = []
+        for i, o in enumerate(outs):
+            nm, nw = min(max(o.n_match, 0), cap), max(o.n_world, 0)
+            pts.append((p1[i, :nm], p2[i, :nm], m[i, :nm], mask[i, :nm], X[i, :, :nw]))
+        return outs, pts
 
 
 class Sequence(Batch):
