@@ -534,3 +534,23 @@ def test_c3_sequence_through_the_sharded_replay(ctx):
     # the chain ends near the true camera position (scale from the altitude / mean depth: a few per cent per step)
     c_true = -sc.Rw[-1].T @ sc.tw[-1]
     assert np.linalg.norm(recs[-1]["estimate_pos"] - c_true) < 0.5 * np.linalg.norm(c_true) + 1.0
+
+
+@pytest.mark.gpu
+def test_bulk_download_equals_the_per_pair_reads(ctx):
+    """vo_batch_get_run_all / vo_batch_get_points_all against vo_batch_get / vo_batch_get_points pair by pair (pairs with
+    different match counts, one of them empty: a black frame)."""
+    scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 1001), (300, 5), (900, 6)]]
+    b = Batch(ctx, 4, 480, 640)
+    for i, sc in enumerate(scenes):
+        b.set_pair(i, sc.img1, sc.img2, synth.K_PARETE)
+    b.set_pair(3, np.zeros((480, 640), np.uint8), scenes[0].img2, synth.K_PARETE)
+    b.run()
+    outs, pts = b.get_all()
+    assert len({o.n_match for o in outs}) >= 3 and outs[3].n_match == 0
+    for i in range(4):
+        assert _rec(outs[i]) == _rec(b.get(i))
+        one = b.get_points(i, cap=max(outs[i].n_match, 1))
+        for got, want in zip(pts[i], one):
+            assert got.shape == want.shape and np.array_equal(got, want)
+    b.close()
