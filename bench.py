@@ -249,7 +249,8 @@ def main():
         n3 = len(c3.frames)
         stamps, alt = 0.1 * np.arange(n3), np.full(n3, 7.0)
         stats = {}
-        replay.replay_sharded(ctx3, c3.frames[: max(8, n3 // 8)], stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev)  # warm-up
+        # warm-up: the same replay once (the context keeps its sequence / pair batches, so the timed run allocates nothing)
+        replay.replay_sharded(ctx3, c3.frames, stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev)
         barrier()
         t3 = time.perf_counter()
         recs = replay.replay_sharded(ctx3, c3.frames, stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev, stats=stats)
@@ -264,7 +265,7 @@ def main():
                   "waves": stats.get("waves"), "gap_pairs": stats.get("gap_pairs"),
                   "end_position_error_m": round(float(np.linalg.norm(last["estimate_pos"] - c_true)), 3),
                   "path_length_m": round(float(sum(c3.relative(k - 1, k)[2] for k in range(1, n3))), 2),
-                  "note": "includes the per-chunk upload of the frames, result read-back, the gather of pair summaries and the host loop"}
+                  "note": "includes the per-chunk upload of the frames, result read-back, the gather of pair summaries and the host loop; second replay of the sequence on a context that keeps its batches (no allocation inside the timed run)"}
         ctx3.close()
 
     extras_out = {}
