@@ -206,7 +206,7 @@ def main():
         batch.run()
         fill(k + 1)
         if k > 0:
-            _ = [batch.get(i, age=1) for i in range(B)]
+            _ = batch.get_records(age=1)
     batch.sync()
     barrier()
     t0 = time.perf_counter()
@@ -214,9 +214,9 @@ def main():
         batch.run()  # upload (copy stream) + kernels of step k
         fill(args.warmup + k + 1)  # pinned staging of step k + 1, beside step k's kernels
         if k > 0:
-            _ = [batch.get(i, age=1) for i in range(B)]  # records of step k - 1: on the host since that step finished
+            _ = batch.get_records(age=1)  # records of step k - 1: on the host since that step finished
     batch.sync()
-    outs = [batch.get(i) for i in range(B)]
+    outs = batch.get_records()
     barrier()
     dt = max_over_ranks(time.perf_counter() - t0)
 
@@ -504,10 +504,10 @@ def run_extras(np, ctx, prm, c2, c1, dev, args):
         b1.run()
         fill1(3 + k)
         if k > 0:
-            _ = [b1.get(i, age=1) for i in range(64)]
+            _ = b1.get_records(age=1)
     b1.sync()
     d1 = time.perf_counter() - t0
-    o1 = [b1.get(i) for i in range(64)]
+    o1 = b1.get_records()
     S1 = layer_samples(480, 640)
     kp1 = float(np.mean([o.n_kp1 for o in o1]))
     alg1 = 2 * (2 * 480 * 640 + 3 * 4 * 481 * 641 + 12 * S1 + 284 * kp1)  # SURVEY 8d "detect total per frame" x 2 frames

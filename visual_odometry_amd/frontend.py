@@ -348,6 +348,12 @@ class Batch:
         self.ctx._chk(self.ctx.lib.vo_batch_get_run(self._h, int(age), i, C.byref(out)))
         return out
 
+    def get_records(self, age: int = 0):
+        """Records of ALL pairs of the latest run (age 0) or of the run before it (age 1) in one call (vo_batch_get_run_all)."""
+        outs = (VoPairOut * self.n_pairs)()
+        self.ctx._chk(self.ctx.lib.vo_batch_get_run_all(self._h, int(age), outs))
+        return list(outs)
+
     def get_points(self, i, cap=None):
         cap = cap or self.ctx.params.match_capacity
         p1 = np.zeros((cap, 2), np.float32)
@@ -365,9 +371,7 @@ class Batch:
     def get_all(self):
         """(records, points) of EVERY pair of the latest run: one wait and one download (vo_batch_get_points_all).  points[i] =
         (p1, p2, matches, mask, Xk) as get_points(i) returns them - views into shared arrays."""
-        outs = (VoPairOut * self.n_pairs)()
-        self.ctx._chk(self.ctx.lib.vo_batch_get_run_all(self._h, 0, outs))
-        outs = list(outs)
+        outs = self.get_records()
         cap = max(1, max(o.n_match for o in outs))
         capw = max(1, max(o.n_world for o in outs))
         P = self.n_pairs
