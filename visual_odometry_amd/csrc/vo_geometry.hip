@@ -1016,36 +1016,35 @@ __global__ __launch_bounds__(64) void k_pose_decompose(PairState* __restrict__ s
 __global__ __launch_bounds__(256) void k_pose_cheirality(PairState* __restrict__ st, int match_cap,
                                                          const float* __restrict__ in1_base, const float* __restrict__ in2_base,
                                                          double dist_thresh) {
-    const int pair = blockIdx.y;
+    // grid = (point blocks, pairs, 4 candidate poses): a thread triangulates its points under ONE candidate (the four DLTs of
+    // a point used to run back to back in one thread: 0.29 ms of latency per launch), and a fixed, small number of blocks per
+    // pair strides over the inliers instead of one block per 256 slots of capacity (most of which only came to leave)
+    const int pair = blockIdx.y, c = blockIdx.z;
     PairState& S = st[pair];
     if (S.niters < 0) return;
     const int n = S.n_inl;
     if (blockIdx.x * 256 >= n) return;
-    const int i = blockIdx.x * 256 + threadIdx.x;
     const int lane = threadIdx.x & 63;
     const double fx = S.K[0], fy = S.K[4], cx = S.K[2], cy = S.K[5];
     const float* in1 = in1_base + (size_t)pair * match_cap * 2;
     const float* in2 = in2_base + (size_t)pair * match_cap * 2;
-    double x1 = 0, y1 = 0, x2 = 0, y2 = 0;
-    if (i < n) {
-        x1 = ((double)in1[2 * i] - cx) / fx;
-        y1 = ((double)in1[2 * i + 1] - cy) / fy;
-        x2 = ((double)in2[2 * i] - cx) / fx;
-        y2 = ((double)in2[2 * i + 1] - cy) / fy;
-    }
     const double P0[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
-    for (int c = 0; c < 4; c++) {
-        const double* Rc = S.Rc[(c == 0 || c == 2) ? 0 : 1];
-        const double sgn = c < 2 ? 1.0 : -1.0;
-        double Pk[12];
+    const double* Rc = S.Rc[(c == 0 || c == 2) ? 0 : 1];
+    const double sgn = c < 2 ? 1.0 : -1.0;
+    double Pk[12];
 #pragma unroll
-        for (int r = 0; r < 3; r++) {
+    for (int r = 0; r < 3; r++) {
 #pragma unroll
-            for (int q = 0; q < 3; q++) Pk[4 * r + q] = Rc[3 * r + q];
-            Pk[4 * r + 3] = sgn * S.tc[r];
-        }
+        for (int q = 0; q < 3; q++) Pk[4 * r + q] = Rc[3 * r + q];
+        Pk[4 * r + 3] = sgn * S.tc[r];
+    }
+    int total = 0;
+    for (int i0 = blockIdx.x * 256; i0 < n; i0 += gridDim.x * 256) {
+        const int i = i0 + threadIdx.x;
         bool good = false;
         if (i < n) {
+            const double x1 = ((double)in1[2 * i] - cx) / fx, y1 = ((double)in1[2 * i + 1] - cy) / fy;
+            const double x2 = ((double)in2[2 * i] - cx) / fx, y2 = ((double)in2[2 * i + 1] - cy) / fy;
             double Q[4];
             dlt_point(P0, Pk, x1, y1, x2, y2, Q);
             bool m = (Q[2] * Q[3] > 0);
@@ -1055,9 +1054,9 @@ __global__ __launch_bounds__(256) void k_pose_cheirality(PairState* __restrict__
             m = m && (z > 0) && (z < dist_thresh);
             good = m;
         }
-        const unsigned long long b = __ballot(good);
-        if (lane == 0 && b) atomicAdd(&S.good[c], __popcll(b));
+        total += __popcll(__ballot(good));
     }
+    if (lane == 0 && total) atomicAdd(&S.good[c], total);
 }
 
 // gate = 1: R/t of the state are overwritten only when VPF >= threshold (optRelativePose);
@@ -1133,10 +1132,10 @@ __global__ __launch_bounds__(256) void k_triang(PairState* __restrict__ st, int 
                 P1[4 * i + j] = s1;
             }
     }
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
     const float* in1 = in1_base + (size_t)pair * match_cap * 2;
     const float* in2 = in2_base + (size_t)pair * match_cap * 2;
+    // the blocks of a pair stride over its points (the batch launches a few blocks per pair, not one per 256 slots of capacity)
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
     const float u1 = in1[2 * i], v1 = in1[2 * i + 1], u2 = in2[2 * i], v2 = in2[2 * i + 1];
     double X[4];
     dlt_point(P0, P1, (double)u1, (double)v1, (double)u2, (double)v2, X);
@@ -1148,7 +1147,7 @@ __global__ __launch_bounds__(256) void k_triang(PairState* __restrict__ st, int 
         h[q] = (float)X[q];
         X4[(size_t)q * ld + i] = h[q];
     }
-    if (Pext) return;
+    if (Pext) continue;
     // my_convertFromHom (float divide, :544) -> CV_64F (:327)
     const double Xw[3] = {(double)(h[0] / h[3]), (double)(h[1] / h[3]), (double)(h[2] / h[3])};
     const double fx = K[0], fy = K[4], cx = K[2], cy = K[5];
@@ -1178,6 +1177,7 @@ __global__ __launch_bounds__(256) void k_triang(PairState* __restrict__ st, int 
     double* Xp = Xpre_base + ((size_t)pair * match_cap + i) * 3;
 #pragma unroll
     for (int r = 0; r < 3; r++) Xp[r] = R[3 * r] * Xw[0] + R[3 * r + 1] * Xw[1] + R[3 * r + 2] * Xw[2] + t[r];  // coordTransf
+    }
 }
 
 // ordered compaction of the kept points, var_avgMat (sequential sums, math_utility.hpp:235-258),
@@ -1425,6 +1425,9 @@ static float thr_sq_of(double thr_px, const double K[9]) {
 // with differing intrinsics the threshold is taken per pair on the device.
 int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o, hipStream_t stream) {
     const int P = ps.P, mc = ps.match_cap;
+    // point blocks per pair of the per-point kernels: a batch strides a few blocks over each pair's points (one block per 256
+    // slots of capacity meant 4096 workgroups of 120-144 VGPRs per launch, most of which only came to leave)
+    const int nbp = P >= 8 ? std::min((mc + 255) / 256, 8) : (mc + 255) / 256;
     if (o.run_ransac) {
         const uint32_t* d_raw = nullptr;
         VO_TRY(rng_table(ctx, o.seed, &d_raw));
@@ -1436,10 +1439,15 @@ int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o, hipStream
                                ps.tuples);
             VO_HIP(hipGetLastError());
         }
-        const int bounds[6] = {0, 64, 256, 1024, 2048, 4096};
-        for (int c = 0; c < 5; c++) {
+        // Hypothesis chunks.  A hypothesis is one wavefront of 136 VGPRs that lives ~0.8 ms whatever the chunk size, so a chunk
+        // of 64 x P wavefronts of a batch holds most of the chip's registers for that long and pushes the detection it runs
+        // beside off the SIMDs (0.5 ms of a 35 ms step), although the adaptive bound is usually reached within a few
+        // hypotheses.  Batches therefore start with 16; a single pair keeps 64 (its chunk is small, and a chunk more is 0.8 ms
+        // of latency when the first one does not suffice).
+        const int bounds[7] = {0, P >= 8 ? 16 : 64, 64, 256, 1024, 2048, 4096};
+        for (int c = 0; c < 6; c++) {
             const int h0 = bounds[c], h1 = std::min(bounds[c + 1], o.max_iters);
-            if (h0 >= h1) break;
+            if (h0 >= h1) continue;  // an empty chunk (a single pair's second bound) or past max_iters
             {
                 StageScope sc(ctx, ST_RANSAC_SOLVE_SCORE, stream);
                 hipLaunchKernelGGL(k_ransac_hyp, dim3(h1 - h0, P), dim3(64), 0, stream, ps.m1, ps.m2, mc, ps.tuples,
@@ -1465,14 +1473,14 @@ int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o, hipStream
         StageScope sc(ctx, ST_POSE, stream);
         hipLaunchKernelGGL(k_pose_decompose, dim3(P), dim3(64), 0, stream, ps.st, ctx->prm.inlier_threshold,
                            o.gate ? 1 : 0);
-        hipLaunchKernelGGL(k_pose_cheirality, dim3((mc + 255) / 256, P), dim3(256), 0, stream, ps.st, mc, ps.in1,
+        hipLaunchKernelGGL(k_pose_cheirality, dim3(nbp, P, 4), dim3(256), 0, stream, ps.st, mc, ps.in1,
                            ps.in2, o.dist_thresh);
         hipLaunchKernelGGL(k_pose_select, dim3(P), dim3(64), 0, stream, ps.st, ctx->prm.vpf_threshold, o.gate ? 1 : 0);
         VO_HIP(hipGetLastError());
     }
     if (o.run_triang) {
         StageScope sc(ctx, ST_TRIANGULATE, stream);
-        hipLaunchKernelGGL(k_triang, dim3((mc + 255) / 256, P), dim3(256), 0, stream, ps.st, mc, ps.in1, ps.in2,
+        hipLaunchKernelGGL(k_triang, dim3(nbp, P), dim3(256), 0, stream, ps.st, mc, ps.in1, ps.in2,
                            (const double*)nullptr, 0, 1, ctx->prm.reprojection_tolerance, ps.X4, ps.Xpre, ps.flag);
         hipLaunchKernelGGL(k_triang_filter, dim3(P), dim3(1024), 0, stream, ps.st, mc, ps.flag, ps.Xpre, ps.tmp,
                            ps.Xk);
