@@ -553,4 +553,10 @@ def test_bulk_download_equals_the_per_pair_reads(ctx):
         one = b.get_points(i, cap=max(outs[i].n_match, 1))
         for got, want in zip(pts[i], one):
             assert got.shape == want.shape and np.array_equal(got, want)
+    # rows too short for the fullest pair: refused as a whole, nothing half-written is reported as success
+    import ctypes as C
+
+    small = np.zeros((4, 1, 2), np.float32)
+    st = ctx.lib.vo_batch_get_points_all(b._h, small.ctypes.data_as(C.POINTER(C.c_float)), None, None, None, 1, None, 0)
+    assert st == -4  # VO_ERR_CAPACITY
     b.close()
