@@ -560,3 +560,27 @@ def test_bulk_download_equals_the_per_pair_reads(ctx):
     st = ctx.lib.vo_batch_get_points_all(b._h, small.ctypes.data_as(C.POINTER(C.c_float)), None, None, None, 1, None, 0)
     assert st == -4  # VO_ERR_CAPACITY
     b.close()
+
+
+def test_batch_hypothesis_chunks_with_hard_pairs(ctx):
+    """Batches of eight pairs or more open RANSAC with a chunk of 16 hypotheses (then 64, 256, ...), a single pair with 64: the
+    same hypotheses in the same order either way, so a batch must reproduce the single-call result bit for bit also when
+    pairs need many iterations - here four pairs whose second frame belongs to ANOTHER scene (few accidental matches, no
+    consensus: the bound never drops) beside four ordinary ones."""
+    scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 31), (600, 32), (800, 33), (500, 34)]]
+    pairs = [(sc.img1, sc.img2) for sc in scenes] + [(scenes[i].img1, scenes[(i + 1) % 4].img2) for i in range(4)]
+    b = Batch(ctx, 8, 480, 640)
+    for i, (a, c) in enumerate(pairs):
+        b.set_pair(i, a, c, synth.K_PARETE)
+    b.run()
+    outs, pts = b.get_all()
+    iters = [o.iters for o in outs]
+    assert min(iters[:4]) < 64 and max(iters[4:]) > 64, iters  # both sides of the chunk bounds are exercised
+    for i, o in enumerate(outs):
+        p1, p2, m, mask, X = pts[i]
+        if len(p1) < 5:
+            continue
+        st, E, smask, ninl, it = ctx.essential_ransac(p1, p2, synth.K_PARETE)
+        assert st == 0 and it == o.iters and ninl == o.n_inl, (i, it, o.iters)
+        assert np.array_equal(mask, smask) and np.array_equal(np.array(o.E).reshape(3, 3), E)
+    b.close()
