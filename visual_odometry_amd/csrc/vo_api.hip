@@ -224,8 +224,11 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         hipStreamCreateWithFlags(&ctx->stream_geo, hipStreamNonBlocking) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_quads, hipEventDisableTiming) != hipSuccess) {
         if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
+        if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
+        if (ctx->ev_quads) hipEventDestroy(ctx->ev_quads);
         if (ctx->stream_aux) hipStreamDestroy(ctx->stream_aux);
         if (ctx->stream_geo) hipStreamDestroy(ctx->stream_geo);
         if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -250,6 +253,7 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
         hipEventDestroy(ctx->ev_fork);
         hipEventDestroy(ctx->ev_join);
+        hipEventDestroy(ctx->ev_quads);
         hipStreamDestroy(ctx->stream_aux);
         hipStreamDestroy(ctx->stream_geo);
         hipStreamDestroy(ctx->stream);
@@ -277,6 +281,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     if (ctx->d_win_pix) hipFree(ctx->d_win_pix);
     hipEventDestroy(ctx->ev_fork);
     hipEventDestroy(ctx->ev_join);
+    hipEventDestroy(ctx->ev_quads);
     hipStreamDestroy(ctx->stream_aux);
     hipStreamDestroy(ctx->stream_geo);
     hipStreamDestroy(ctx->stream);

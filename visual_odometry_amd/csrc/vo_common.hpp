@@ -190,6 +190,7 @@ struct vo_ctx {
     hipStream_t stream_aux = nullptr;  // the largest descriptor class runs here, beside the other three (its long keypoints
                                        // leave a tail in which most CUs idle); joined before the matcher
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_quads = nullptr;     // the footprint image of the current detection is complete (auxiliary stream)
     hipStream_t stream_geo = nullptr;  // RANSAC / pose / triangulation of a batch run here, under the next run's detection
     DetectTables* d_tables = nullptr;
     void* d_win_cell = nullptr;     // INTER_AREA decimation tables of every window size (vo_detect.hip: CellTab [769][21 + 1])

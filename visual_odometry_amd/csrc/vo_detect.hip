@@ -2241,6 +2241,23 @@ int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_
 int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
     VO_TRY(vo_enqueue_integral(ctx, fs));
     VO_TRY(vo_enqueue_hessian_nms(ctx, fs, describe, nullptr));
+    // The footprint image of the descriptor sampler depends on the frame only: it is built on the auxiliary stream beside the
+    // sort (one workgroup per frame: half the CUs idle) and the orientation pass (VALU-bound, while this is a streaming pass).
+    // With the stage timers on it stays in its stage on the main stream.
+    const bool quads_beside = describe && !ctx->profiling;
+    auto launch_quads = [&](hipStream_t st) {
+        if (fs.W % 4 == 0 && fs.img_stride() % 4 == 0)
+            hipLaunchKernelGGL(k_quads4, dim3((fs.W / 4 + 255) / 256, fs.H, fs.F), dim3(256), 0, st, fs.img, fs.img_stride(), fs.H, fs.W,
+                               fs.quad);
+        else
+            hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, st, fs.img, fs.img_stride(), fs.H, fs.W, fs.quad);
+    };
+    if (quads_beside) {
+        VO_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+        VO_HIP(hipStreamWaitEvent(ctx->stream_aux, ctx->ev_fork, 0));
+        launch_quads(ctx->stream_aux);
+        VO_HIP(hipEventRecord(ctx->ev_quads, ctx->stream_aux));
+    }
     {
         StageScope sc(ctx, ST_SORT);
         hipLaunchKernelGGL(k_count_clamp, dim3((fs.F + 255) / 256), dim3(256), 0, ctx->stream, fs.cnt, fs.cap, fs.F);
@@ -2276,12 +2293,10 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
                 hipLaunchKernelGGL(k_classify_scan, dim3(4), dim3(1024), 0, ctx->stream, nkeys, fs.cls_hist, fs.cls_cnt);
                 hipLaunchKernelGGL(k_classify_scatter, gk, dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt, fs.W, nbins, nkeys,
                                    fs.cls_hist, fs.cls_list, ls);
-                if (fs.W % 4 == 0 && fs.img_stride() % 4 == 0)
-                    hipLaunchKernelGGL(k_quads4, dim3((fs.W / 4 + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img,
-                                       fs.img_stride(), fs.H, fs.W, fs.quad);
+                if (quads_beside)
+                    VO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_quads, 0));
                 else
-                    hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, ctx->stream, fs.img,
-                                       fs.img_stride(), fs.H, fs.W, fs.quad);
+                    launch_quads(ctx->stream);
             }
 #define LAUNCH_TILED(STAGE, HI, NW, RB, UMAX, G, CH, CLS, GRID, STREAM)                                                             \
     {                                                                                                                              \
