@@ -225,10 +225,12 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         hipStreamCreateWithFlags(&ctx->stream_aux, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_fork, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&ctx->ev_join, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&ctx->ev_quads, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&ctx->ev_quads, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&ctx->ev_integral, hipEventDisableTiming) != hipSuccess) {
         if (ctx->ev_fork) hipEventDestroy(ctx->ev_fork);
         if (ctx->ev_join) hipEventDestroy(ctx->ev_join);
         if (ctx->ev_quads) hipEventDestroy(ctx->ev_quads);
+        if (ctx->ev_integral) hipEventDestroy(ctx->ev_integral);
         if (ctx->stream_aux) hipStreamDestroy(ctx->stream_aux);
         if (ctx->stream_geo) hipStreamDestroy(ctx->stream_geo);
         if (ctx->stream) hipStreamDestroy(ctx->stream);
@@ -254,6 +256,7 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         hipEventDestroy(ctx->ev_fork);
         hipEventDestroy(ctx->ev_join);
         hipEventDestroy(ctx->ev_quads);
+        hipEventDestroy(ctx->ev_integral);
         hipStreamDestroy(ctx->stream_aux);
         hipStreamDestroy(ctx->stream_geo);
         hipStreamDestroy(ctx->stream);
@@ -282,6 +285,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     hipEventDestroy(ctx->ev_fork);
     hipEventDestroy(ctx->ev_join);
     hipEventDestroy(ctx->ev_quads);
+    hipEventDestroy(ctx->ev_integral);
     hipStreamDestroy(ctx->stream_aux);
     hipStreamDestroy(ctx->stream_geo);
     hipStreamDestroy(ctx->stream);
@@ -383,7 +387,7 @@ extern "C" int vo_integral(vo_ctx* ctx, const uint8_t* img, int rows, int cols, 
     VO_HIP(hipSetDevice(ctx->device));
     VO_TRY(vo_frameset_alloc(ctx->fs, 1, rows, cols, ctx->prm.kp_capacity));
     VO_TRY(upload_frame(ctx, ctx->fs, 0, img, step));
-    VO_TRY(vo_enqueue_integral(ctx, ctx->fs));
+    VO_TRY(vo_enqueue_integral(ctx, ctx->fs, ctx->stream));
     VO_HIP(hipMemcpyAsync(sum, ctx->fs.sum, ctx->fs.sum_stride() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(hipStreamSynchronize(ctx->stream));
     return VO_OK;
@@ -397,7 +401,7 @@ extern "C" int vo_hessian_layer(vo_ctx* ctx, const uint8_t* img, int rows, int c
     VO_HIP(hipSetDevice(ctx->device));
     VO_TRY(vo_frameset_alloc(ctx->fs, 1, rows, cols, ctx->prm.kp_capacity));
     VO_TRY(upload_frame(ctx, ctx->fs, 0, img, step));
-    VO_TRY(vo_enqueue_integral(ctx, ctx->fs));
+    VO_TRY(vo_enqueue_integral(ctx, ctx->fs, ctx->stream));
     const size_t n = (size_t)(rows >> octave) * (cols >> octave);
     void* tmp = nullptr;
     VO_TRY(vo_ctx_tmp(ctx, 2 * n * sizeof(float) + 16, &tmp));
@@ -424,7 +428,7 @@ extern "C" int vo_hessian_product_det(vo_ctx* ctx, const uint8_t* img, int rows,
     VO_TRY(vo_frameset_alloc(fs, 1, rows, cols, ctx->prm.kp_capacity));
     VO_TRY(reset_counters(ctx, fs));
     VO_TRY(upload_frame(ctx, fs, 0, img, step));
-    VO_TRY(vo_enqueue_integral(ctx, fs));
+    VO_TRY(vo_enqueue_integral(ctx, fs, ctx->stream));
     void* tmp = nullptr;
     VO_TRY(vo_ctx_tmp(ctx, S * sizeof(float), &tmp));
     VO_HIP(hipMemsetAsync(tmp, 0xff, S * sizeof(float), ctx->stream));  // NaN pattern: a sample no tile wrote would show
@@ -1063,6 +1067,7 @@ extern "C" int vo_batch_run(vo_batch* b) {
     }
     std::memcpy(rh.init, b->h_init.data(), b->h_init.size() * sizeof(PairState));
     std::memcpy(rh.frames, b->h_frames.data(), b->h_frames.size() * sizeof(int2));
+    hipEvent_t img_ready = nullptr;
     if (b->n_staged > 0) {  // frames were staged since the latest run: this run reads the other slot
         const int s = b->fill_slot;
         const size_t fst = b->fs.img_stride();
@@ -1079,7 +1084,12 @@ extern "C" int vo_batch_run(vo_batch* b) {
         }
         VO_HIP(hipEventRecord(b->ev_h2d[s], b->stream_copy));
         b->h2d_pending[s] = true;
-        VO_HIP(hipStreamWaitEvent(ctx->stream, b->ev_h2d[s], 0));
+        img_ready = b->ev_h2d[s];  // the detection waits for it on the stream its integral pass runs on
+        // frames written by vo_prep_to_batch (kernels on the main stream): the auxiliary stream has to see them too
+        if (std::find(b->staged.begin(), b->staged.end(), (uint8_t)1) != b->staged.end()) {
+            VO_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
+            VO_HIP(hipStreamWaitEvent(ctx->stream_aux, ctx->ev_fork, 0));
+        }
         b->cur_slot = s;
         b->fill_slot = s ^ 1;
         b->n_staged = 0;
@@ -1097,7 +1107,7 @@ extern "C" int vo_batch_run(vo_batch* b) {
         if (b->runs >= 2) VO_HIP(hipStreamWaitEvent(ctx->stream, rh.ev_done, 0));
     }
     VO_TRY(reset_counters(ctx, b->fs));
-    VO_TRY(vo_enqueue_detect(ctx, b->fs, true));
+    VO_TRY(vo_enqueue_detect(ctx, b->fs, true, true, img_ready));
     VO_HIP(hipEventRecord(b->ev_img_free[b->cur_slot], ctx->stream));
     b->img_free_pending[b->cur_slot] = true;
     // Everything from the matcher on goes to the geometry stream, in order behind the previous run's geometry (which may still

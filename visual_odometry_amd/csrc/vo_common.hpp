@@ -191,6 +191,7 @@ struct vo_ctx {
                                        // leave a tail in which most CUs idle); joined before the matcher
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_quads = nullptr;     // the footprint image of the current detection is complete (auxiliary stream)
+    hipEvent_t ev_integral = nullptr;  // the integral image of the current detection is complete (auxiliary stream, batch runs)
     hipStream_t stream_geo = nullptr;  // RANSAC / pose / triangulation of a batch run here, under the next run's detection
     DetectTables* d_tables = nullptr;
     void* d_win_cell = nullptr;     // INTER_AREA decimation tables of every window size (vo_detect.hip: CellTab [769][21 + 1])
@@ -300,9 +301,9 @@ struct StageScope {  // records HIP events around a stage when profiling is on
 // ---------------------------------------------------------------- kernels' host launchers
 // vo_detect.hip
 void vo_build_detect_tables(DetectTables& t, int sum_cols_unused);
-int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs);
+int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs, hipStream_t stream);
 int vo_enqueue_hessian_layer(vo_ctx* ctx, FrameSet& fs, int frame, int octave, int layer, float* d_det, float* d_trace);
-int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe);
+int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_beside = false, hipEvent_t img_ready = nullptr);
 int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_det);
 // vo_match.hip
 // every launch goes to `stream` (the main stream for the single-call entry points, the geometry stream for a batch)

@@ -449,34 +449,34 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     }
 }
 
-int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs) {
-    StageScope sc(ctx, ST_INTEGRAL);
+int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs, hipStream_t stream) {
+    StageScope sc(ctx, ST_INTEGRAL, stream);
     const int nbands = (fs.H + kBand - 1) / kBand;
     dim3 g1((fs.W + 255) / 256, nbands, fs.F);
     const bool aligned4 = fs.W % 4 == 0 && fs.img_stride() % 4 == 0;
     if (aligned4)
-        hipLaunchKernelGGL(k_colsum4, dim3((nbands * (fs.W / 4) + 255) / 256, 1, fs.F), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+        hipLaunchKernelGGL(k_colsum4, dim3((nbands * (fs.W / 4) + 255) / 256, 1, fs.F), dim3(256), 0, stream, fs.img, fs.img_stride(),
                            fs.H, fs.W, nbands, fs.colsum);
     else
-        hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
-    hipLaunchKernelGGL(k_colsum_scan, dim3((fs.W + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.W, nbands, fs.colsum);
+        hipLaunchKernelGGL(k_colsum, g1, dim3(256), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum);
+    hipLaunchKernelGGL(k_colsum_scan, dim3((fs.W + 255) / 256, fs.F), dim3(256), 0, stream, fs.W, nbands, fs.colsum);
     dim3 g2(nbands, fs.F);
     if (aligned4) {
         if (fs.W <= 1024)
-            hipLaunchKernelGGL((k_integral4<256, false>), g2, dim3(256), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
+            hipLaunchKernelGGL((k_integral4<256, false>), g2, dim3(256), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
                                fs.sum, fs.sum_stride());
         else if (fs.W <= 2048)
-            hipLaunchKernelGGL((k_integral4<512, false>), g2, dim3(512), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
+            hipLaunchKernelGGL((k_integral4<512, false>), g2, dim3(512), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
                                fs.sum, fs.sum_stride());
         else
-            hipLaunchKernelGGL((k_integral4<512, true>), g2, dim3(512), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
+            hipLaunchKernelGGL((k_integral4<512, true>), g2, dim3(512), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
                                fs.sum, fs.sum_stride());
         VO_HIP(hipGetLastError());
         return VO_OK;
     }
     const int cpt = (fs.W + 1023) / 1024;
 #define LAUNCH_INT(C)                                                                                              \
-    hipLaunchKernelGGL(k_integral<C>, g2, dim3(1024), 0, ctx->stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, \
+    hipLaunchKernelGGL(k_integral<C>, g2, dim3(1024), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, \
                        fs.colsum, fs.sum, fs.sum_stride())
     if (cpt <= 1)
         LAUNCH_INT(1);
@@ -1342,7 +1342,7 @@ template <int WLO, int WHI, int NT>
 __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                  const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                  vo_keypoint* __restrict__ kp_base, float* __restrict__ desc_base,
-                                                 int cap, const int* __restrict__ list, int* __restrict__ cls_cnt, int cls) {
+                                                 int cap, const int* __restrict__ list, int* __restrict__ cls_cnt, int cls, int have_dir) {
     __shared__ float2 s_XY[kOriSamples + 15];
     __shared__ int s_A[kOriSamples + 15];
     __shared__ CellTab s_cell[kPatch + 1];
@@ -1376,7 +1376,13 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
 
     // ---------------------------------------------------------------- orientation (A.5), first wavefront
-    if (tid < 64) describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_XY, s_A, kpp, &s_dir);
+    // (have_dir: k_orientation has run and the record holds the direction - the same function gave it; the integral image is
+    // then not read here, so the NEXT detection's integral pass may already be overwriting it on the auxiliary stream)
+    if (have_dir) {
+        if (tid == 0) s_dir = kpp->angle;
+    } else if (tid < 64) {
+        describe_orientation(sum, sw, H, W, cx, cy, s, lane, tid, s_XY, s_A, kpp, &s_dir);
+    }
     // ---------------------------------------------------------------- decimation tables (A.6.1)
     const double scale = (double)win / (kPatch + 1);
     const int iscale = d_cvRoundD(scale);
@@ -2238,8 +2244,21 @@ int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_
     return VO_OK;
 }
 
-int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
-    VO_TRY(vo_enqueue_integral(ctx, fs));
+int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_beside, hipEvent_t img_ready) {
+    // integral_beside (batch runs): the integral pass - a streaming pass that needs nothing but the frames - goes to the
+    // auxiliary stream, which idles through the second half of the PREVIOUS run's description (its one launch there ends
+    // early), so it runs under that run's VALU-bound descriptor kernels instead of after them.  Nothing of the previous run
+    // reads the integral image by then: orientation and NMS are over before the auxiliary stream's descriptor launch starts,
+    // and the sequential fallback takes its directions from the keypoint records.  img_ready: the frames' upload (may be null).
+    if (integral_beside && describe && !ctx->profiling) {
+        if (img_ready) VO_HIP(hipStreamWaitEvent(ctx->stream_aux, img_ready, 0));
+        VO_TRY(vo_enqueue_integral(ctx, fs, ctx->stream_aux));
+        VO_HIP(hipEventRecord(ctx->ev_integral, ctx->stream_aux));
+        VO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_integral, 0));
+    } else {
+        if (img_ready) VO_HIP(hipStreamWaitEvent(ctx->stream, img_ready, 0));
+        VO_TRY(vo_enqueue_integral(ctx, fs, ctx->stream));
+    }
     VO_TRY(vo_enqueue_hessian_nms(ctx, fs, describe, nullptr));
     // The footprint image of the descriptor sampler depends on the frame only: it is built on the auxiliary stream beside the
     // sort (one workgroup per frame: half the CUs idle) and the orientation pass (VALU-bound, while this is a streaming pass).
@@ -2328,7 +2347,7 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe) {
                 // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
                 StageScope sc(ctx, ST_DESC_SEQ);
                 hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
-                                   fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4);
+                                   fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4, 1);
             }
             VO_HIP(hipGetLastError());
         }
