@@ -101,6 +101,14 @@ extern "C" int vo_stage_count(void) { return ST_COUNT; }
 extern "C" const char* vo_stage_name(int s) { return (s >= 0 && s < ST_COUNT) ? kStageNames[s] : ""; }
 extern "C" int vo_profile_enable(vo_ctx* ctx, int on) {
     if (!ctx) return VO_ERR_INVALID_ARG;
+    if (ctx->profiling != (on != 0)) {
+        // The two modes order their launches differently (with the timers on everything is serialised on the main stream;
+        // otherwise the auxiliary stream's order carries dependencies between consecutive runs): drain before switching
+        VO_HIP(hipSetDevice(ctx->device));
+        VO_HIP(hipStreamSynchronize(ctx->stream));
+        VO_HIP(hipStreamSynchronize(ctx->stream_aux));
+        VO_HIP(hipStreamSynchronize(ctx->stream_geo));
+    }
     ctx->profiling = on != 0;
     return VO_OK;
 }
