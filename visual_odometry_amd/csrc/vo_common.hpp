@@ -187,8 +187,11 @@ struct vo_ctx {
     vo_params prm;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t stream_aux = nullptr;  // the largest descriptor class runs here, beside the other three (its long keypoints
-                                       // leave a tail in which most CUs idle); joined before the matcher
+    // Auxiliary stream, in order per run: [batch runs: the integral pass, which thereby runs under the PREVIOUS run's
+    // descriptor kernels] -> Hessian octave 1 (beside the octave-0 grid) -> the footprint image (beside sort and orientation)
+    // -> the largest descriptor class (beside the other three: its long keypoints leave a tail in which most CUs idle).
+    // Forked / joined with the main stream by events; unused while the stage timers are on.
+    hipStream_t stream_aux = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipEvent_t ev_quads = nullptr;     // the footprint image of the current detection is complete (auxiliary stream)
     hipEvent_t ev_integral = nullptr;  // the integral image of the current detection is complete (auxiliary stream, batch runs)
