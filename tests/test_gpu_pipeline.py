@@ -584,3 +584,16 @@ def test_batch_hypothesis_chunks_with_hard_pairs(ctx):
         assert st == 0 and it == o.iters and ninl == o.n_inl, (i, it, o.iters)
         assert np.array_equal(mask, smask) and np.array_equal(np.array(o.E).reshape(3, 3), E)
     b.close()
+
+
+def test_cxx_host_program_runs_the_pipelined_loop():
+    """examples/batch_pipeline.cpp (built by __graft_entry__.build()): the pipelined batch loop of INTEGRATION.md from a C++
+    host on the C ABI; the program compares every pipelined step with a synchronous run and exits non-zero on a difference."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "batch_pipeline")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "records differing from the synchronous runs: 0" in out.stdout and "4 of 4 pairs with a pose" in out.stdout, out.stdout
