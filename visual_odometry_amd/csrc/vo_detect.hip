@@ -589,31 +589,48 @@ __device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o
     }
     if (tid == 0) s_queue[0] = 0;
     __syncthreads();
-    for (int l = 1; l <= 3; l++) {
-        const int size_next = c_tab.layers[o * kLayersPerOctave + l + 1].size;
-        const int margin = (size_next / 2) / step + 1;
+    // (sample loop outside, layers inside: a sample's tile coordinates and frame position are computed once for its three
+    // layers; the order in which candidates reach the queue is irrelevant)
+    int margin_l[3];
+#pragma unroll
+    for (int l = 1; l <= 3; l++) margin_l[l - 1] = (c_tab.layers[o * kLayersPerOctave + l + 1].size / 2) / step + 1;
+    // tiles away from the frame border (all but the outermost ring): every sample is inside every layer's margin, no per-sample
+    // bounds tests
+    const int mmax = margin_l[2];
+    const bool inner = ty * TI >= mmax && (ty + 1) * TI <= lrows - mmax && tx * TI >= mmax && (tx + 1) * TI <= lcols - mmax;
+    auto pass1 = [&](auto inner_c) {
+        constexpr bool INNER = decltype(inner_c)::value;
         for (int s0 = 0; s0 < TI * TI; s0 += NT) {
             const int s = s0 + tid;
             const int yy = s / TI, xx = s - yy * TI;
             const int i = ty * TI + yy, j = tx * TI + xx;
-            bool cand = false;
-            if (s < TI * TI && i >= margin && i < lrows - margin && j >= margin && j < lcols - margin) {
-                const float* p = s_det + l * PLANE + (yy + 1) * DP + (xx + 1);
-                const float v = p[0];
-                if (v > thr)
-                    cand = v > p[-DP - 1] && v > p[-DP] && v > p[-DP + 1] && v > p[-1] && v > p[1] && v > p[DP - 1] && v > p[DP] &&
-                           v > p[DP + 1];
-            }
-            const unsigned long long m = __ballot(cand);
-            if (m) {
-                int base = 0;
-                if (lane == 0) base = atomicAdd(&s_queue[0], __popcll(m));
-                base = __shfl(base, 0, 64);
-                const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
-                if (cand && pos < kNmsQueue) s_queue[1 + pos] = (l << 20) | (yy << 10) | xx;
+            const float* p0 = s_det + (yy + 1) * DP + (xx + 1);
+#pragma unroll
+            for (int l = 1; l <= 3; l++) {
+                const int margin = margin_l[l - 1];
+                bool cand = false;
+                if (s < TI * TI && (INNER || (i >= margin && i < lrows - margin && j >= margin && j < lcols - margin))) {
+                    const float* p = p0 + l * PLANE;
+                    const float v = p[0];
+                    if (v > thr)
+                        cand = v > p[-DP - 1] && v > p[-DP] && v > p[-DP + 1] && v > p[-1] && v > p[1] && v > p[DP - 1] && v > p[DP] &&
+                               v > p[DP + 1];
+                }
+                const unsigned long long m = __ballot(cand);
+                if (m) {
+                    int base = 0;
+                    if (lane == 0) base = atomicAdd(&s_queue[0], __popcll(m));
+                    base = __shfl(base, 0, 64);
+                    const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+                    if (cand && pos < kNmsQueue) s_queue[1 + pos] = (l << 20) | (yy << 10) | xx;
+                }
             }
         }
-    }
+    };
+    if (inner)
+        pass1(std::true_type{});
+    else
+        pass1(std::false_type{});
     __syncthreads();
     const int nq = min(s_queue[0], kNmsQueue);
     for (int q0 = 0; q0 < nq; q0 += NT) {
