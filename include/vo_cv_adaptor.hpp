@@ -12,13 +12,47 @@
 #pragma once
 #include <opencv2/core.hpp>
 
+#include <cstdlib>
+#include <memory>
+
 #include "vo_frontend.hpp"
 
 namespace vo_cv {
 
+// Where the algorithm parameters come from.  The reference keeps them in mutable header globals (camera_utility.hpp:33-63:
+// minHessian, ratio_thresh, width_low ... height_high, ransac_prob[], ransac_threshold[], inlier_threshold[], VPF_threshold,
+// distance_threshold, reprojection_tolerance); integration/ros/vo_mi355x_switch_end.hpp, which is included after that header
+// and therefore sees them, registers a provider that reads them.  Without a provider the library's defaults (the same
+// values) apply.
+using ParamsProvider = vo_params (*)();
+inline ParamsProvider& params_provider() {
+    static ParamsProvider p = nullptr;
+    return p;
+}
+inline void set_params_provider(ParamsProvider p) { params_provider() = p; }
+
+inline int hip_device_from_env() {  // VO_HIP_DEVICE picks the GPU of the node's context (default 0)
+    const char* e = std::getenv("VO_HIP_DEVICE");
+    return e && *e ? std::atoi(e) : 0;
+}
+
+// One context per process: the node is single-threaded (visual_Odometry.cpp:179-480).  The provider is asked on every call
+// (a few loads); when a global has changed since the context was made - the reference's are plain non-const ints - the
+// context is rebuilt with the new values, so an edited ROI or threshold takes effect exactly as it would in the reference.
 inline vo::Frontend& frontend() {
-    static vo::Frontend f;  // one context per process: the node is single-threaded (visual_Odometry.cpp:179-480)
-    return f;
+    static std::unique_ptr<vo::Frontend> f;
+    static vo_params live;
+    vo_params want;
+    if (params_provider())
+        want = params_provider()();
+    else
+        vo_params_default(&want);
+    if (!f || std::memcmp(&want, &live, sizeof(want)) != 0) {
+        f.reset();  // the old context goes first: one context per GPU at a time
+        f.reset(new vo::Frontend(&want, hip_device_from_env()));
+        live = want;
+    }
+    return *f;
 }
 
 inline vo::Image view(const cv::Mat& m) {

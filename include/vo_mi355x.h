@@ -177,7 +177,8 @@ int vo_triang_points(vo_ctx* ctx, const float* in1xy, const float* in2xy, int n,
                      double* Xk, int cap, int* m);
 
 /* ---- triangPoints without any allocation.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot allocate
- * device memory - code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc.  Same arguments,
+ * device memory - tight serving loops, harnesses that forbid hipMalloc (the call still copies through the context's pinned
+ * buffers and waits on the context's stream, so it cannot itself be CAPTURED into a HIP graph).  Same arguments,
  * results and status codes as vo_triang_points (bit-identical output), but every intermediate lives in a static device
  * array of the library (1.77 MiB per GPU, held until the process ends) and the host staging goes through the pinned
  * buffers vo_ctx_create made: the call issues no hipMalloc / hipFree / hipHostMalloc.  Limits: n <= VO_NOALLOC_MAX_POINTS,
@@ -213,8 +214,9 @@ void vo_batch_destroy(vo_batch* b);
  * replaced between two runs carry over; every run starts every pair from R = I, t = 0.                                 */
 int vo_batch_set_pair(vo_batch* b, int pair, const uint8_t* img1, size_t step1,
                       const uint8_t* img2, size_t step2, const double K[9]);
-/* enqueue the whole pipeline for all pairs on the frames staged so far; returns without waiting.  VO_ERR_INVALID_ARG when
- * a pair has no camera matrix yet (K[0] or K[4] zero).                                                                  */
+/* enqueue the whole pipeline for all pairs on the frames staged so far; returns without waiting.  A pair that has no
+ * camera matrix yet (K[0] or K[4] zero: no vo_batch_set_pair / vo_batch_set_k / vo_seq_set_pair for it) does not fail the
+ * run: its own record comes back with status VO_ERR_INVALID_ARG and success 0, the other pairs run as usual.            */
 int vo_batch_run(vo_batch* b);
 /* wait for the uploads issued so far and for the latest run                                                            */
 int vo_batch_sync(vo_batch* b);
@@ -236,11 +238,30 @@ int vo_batch_get_points(vo_batch* b, int pair, float* p1xy, float* p2xy, vo_dmat
 int vo_batch_get_points_all(vo_batch* b, float* p1xy, float* p2xy, vo_dmatch* m, uint8_t* mask, int cap, double* Xk,
                             int cap_world);
 
+/* ---- multi-GPU: vo_pair_batch(ctx_per_gpu[], n_gpu, pairs, n_pairs, out).  Replaces, for offline batches,
+ * the node's single sequential loop over frame pairs (src/visual_Odometry.cpp:268-470: opt_DetectFeatures :296,
+ * optRelativePose :336, triangPoints :384 once per iteration).  One host thread per context (the calling thread drives the
+ * first one), pair p runs on context p mod n_ctx through that context's pipelined batch loop (uploads beside kernels, steps
+ * of up to 64 pairs at 1080p), and every thread writes its records into out[p] - a host gather, nothing crosses between
+ * GPUs.  Contexts are normally one per GPU (vo_ctx_create(params, g, &ctx[g]) for g < vo_device_count()); several contexts
+ * on one GPU are allowed.  Frames are cv::Mat-style CV_8UC1 buffers, all of one size; records are bit-identical to those of
+ * a single context running the same pairs.  Returns the first failing context's status (text: vo_last_hip_error).      */
+typedef struct vo_pair_in {
+    const uint8_t* img1;    /* prev_img: data, step of a CV_8UC1 cv::Mat          */
+    size_t step1;
+    const uint8_t* img2;    /* curr_img                                            */
+    size_t step2;
+    int32_t rows, cols;     /* the same for every pair of a call                   */
+    double K[9];            /* camera matrix, row-major                            */
+} vo_pair_in;
+int vo_device_count(void);  /* HIP devices visible to the process (0 when there is no runtime / device) */
+int vo_pair_batch(vo_ctx* const* ctx_per_gpu, int n_ctx, const vo_pair_in* pairs, int n_pairs, vo_pair_out* out);
+
 /* Sequence batch (offline replay of consecutive frames; no counterpart in the reference, which re-detects prev_img
  * in every iteration, src/visual_Odometry.cpp:296): n_frames frames are detected and described once each;
  * n_frames - 1 pairs, pair p = (frame p, frame p + 1) unless vo_seq_set_pair re-pairs it (the NOT_MOVING case keeps
- * prev_img, :316-326).  vo_seq_set_pair must be called for every pair to give its K.  Run / sync / get / get_points /
- * destroy are the vo_batch_* calls.                                                                              */
+ * prev_img, :316-326).  vo_seq_set_pair gives a pair its K; a pair without one reports VO_ERR_INVALID_ARG in its own
+ * record (see vo_batch_run).  Run / sync / get / get_points / destroy are the vo_batch_* calls.                  */
 int vo_seq_create(vo_ctx* ctx, int n_frames, int rows, int cols, vo_batch** out);
 int vo_seq_set_frame(vo_batch* b, int frame, const uint8_t* img, size_t step);
 int vo_seq_set_pair(vo_batch* b, int pair, int frame_a, int frame_b, const double K[9]);

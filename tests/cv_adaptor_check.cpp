@@ -12,7 +12,18 @@ using namespace cv;
 using namespace std;
 
 #include "vo_mi355x_switch_begin.hpp"
-// ---- what camera_utility.hpp declares (signatures only: :73-78, :147, :742, :633, :288)
+// ---- what camera_utility.hpp declares: its parameter globals (names and types of :21, :33-63; the switch-end header reads
+// them) and the signatures :73-78, :147, :742, :633, :288
+enum rel_pose_method { ESSENTIAL, HOMOGRAPHY };
+int minHessian = 50, nOctaves = 4, nOctaveLayers = 3;
+bool extended = false, upright = false;
+const float ratio_thresh = 0.7f;
+int width_low = 28, height_low = 20, width_high = 614, height_high = 482;
+double ransac_prob[] = {0.99, 0.99}, ransac_threshold[] = {2.0, 5.0};
+const float inlier_threshold[] = {0.3, 0.3};
+const float VPF_threshold = 0.85;
+const double distance_threshold = 50.0;
+const float reprojection_tolerance = 0.5;
 struct KpAsPoint2f_Match {
     vector<Point2f> Kpoints1;
     vector<Point2f> Kpoints2;
@@ -97,5 +108,27 @@ int main(int argc, char** argv) {
     Mat wp;
     if (success) wp = triangPoints(inlier_converted.Kpoints1, inlier_converted.Kpoints2, R, t, K);
     printf("matches %zu inliers %zu success %d world points %d\n", kP_converted.Kpoints1.size(), inlier_converted.Kpoints1.size(), (int)success, wp.cols);
-    return kP_converted.Kpoints1.size() > 50 ? 0 : 1;
+    // the node's globals are the parameters: a narrower ROI (camera_utility.hpp:44-47 are plain ints) must narrow the matches,
+    // a higher minHessian must thin the keypoints, and restoring them must restore the first result
+    const size_t n_all = kP_converted.Kpoints1.size();
+    size_t left_of_300 = 0;
+    for (const Point2f& p : kP_converted.Kpoints1) left_of_300 += p.x < 300.f;
+    width_low = 300;
+    KpAsPoint2f_Match narrow;
+    opt_DetectFeatures(prev_img, curr_img, narrow);
+    bool roi_ok = narrow.Kpoints1.size() + left_of_300 == n_all && left_of_300 > 0;
+    for (const Point2f& p : narrow.Kpoints1) roi_ok = roi_ok && p.x >= 300.f;
+    width_low = 28;
+    minHessian = 5000;
+    KpAsPoint2f_Match sparse;
+    opt_DetectFeatures(prev_img, curr_img, sparse);
+    const bool hess_ok = sparse.Kpoints1.size() < n_all;
+    minHessian = 50;
+    KpAsPoint2f_Match again;
+    opt_DetectFeatures(prev_img, curr_img, again);
+    bool same = again.Kpoints1.size() == n_all;
+    for (size_t i = 0; same && i < n_all; i++) same = again.Kpoints1[i].x == kP_converted.Kpoints1[i].x && again.Kpoints2[i].y == kP_converted.Kpoints2[i].y;
+    printf("globals: roi %s (%zu of %zu matches right of x = 300) minHessian %s (%zu matches at 5000) restored %s\n", roi_ok ? "ok" : "BAD",
+           narrow.Kpoints1.size(), n_all, hess_ok ? "ok" : "BAD", sparse.Kpoints1.size(), same ? "ok" : "BAD");
+    return kP_converted.Kpoints1.size() > 50 && roi_ok && hess_ok && same ? 0 : 1;
 }

@@ -199,6 +199,25 @@ def test_lz4_block_and_frame_decoding_against_hand_made_streams():
     bad[-1] ^= 1
     with pytest.raises(ValueError):
         bagio.lz4_frame_decode(bytes(bad))  # content checksum
+    # the plain-Python XXH32 (header checksum, and every checksum when the xxhash module is absent) against the module
+    import xxhash
+
+    for n in (0, 1, 3, 4, 15, 16, 17, 63, 64, 1000):
+        d = bytes((7 * i + n) & 255 for i in range(n))
+        assert bagio._xxh32(d) == xxhash.xxh32(d, seed=0).intdigest(), n
+    bad = bytearray(frame)
+    bad[6] ^= 0x10
+    with pytest.raises(ValueError, match="header checksum"):
+        bagio.lz4_frame_decode(bytes(bad))
+    for cut in (5, 6, 9, len(frame) - 9, len(frame) - 2):  # truncation is a ValueError, never IndexError / struct.error
+        with pytest.raises(ValueError):
+            bagio.lz4_frame_decode(frame[:cut])
+    with pytest.raises(ValueError):
+        bagio.lz4_block_decode(bytes([0x50]) + b"hel")  # literal run past the end
+    with pytest.raises(ValueError):
+        bagio.lz4_block_decode(bytes([0x35]) + b"abc" + b"\x03")  # match offset cut in half
+    with pytest.raises(ValueError, match="larger than declared"):
+        bagio.lz4_block_decode(bytes([0x50]) + b"hello", max_out=4)  # literals-only last sequence over the maximum
 
 
 def _handmade_bag(compression):

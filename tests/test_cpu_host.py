@@ -28,6 +28,8 @@ def test_struct_layouts_match_header():
 
     assert C.sizeof(_abi.VoKeypoint) == 28 and C.sizeof(_abi.VoDMatch) == 16
     assert C.sizeof(_abi.VoPairOut) == 10 * 4 + 21 * 8
+    assert C.sizeof(_abi.VoPairIn) == 4 * 8 + 2 * 4 + 9 * 8  # vo_pair_in of vo_pair_batch
+    assert _abi.VoPairIn.rows.offset == 32 and _abi.VoPairIn.K.offset == 40
     lib = _abi.load_library()
     p = _abi.VoParams()
     lib.vo_params_default(C.byref(p))
@@ -168,3 +170,17 @@ def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"] and cmd[-7].endswith("bench.py")
     assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
     assert ("torch" in sys.modules) == torch_loaded_before  # launching did not pull torch into the parent
+
+
+def test_pair_batch_argument_checks_need_no_gpu():
+    """vo_pair_batch rejects bad arguments before any thread or HIP call; vo_device_count is 0 without a device."""
+    from visual_odometry_amd import _abi
+
+    lib = _abi.load_library()
+    outs = (_abi.VoPairOut * 1)()
+    ins = (_abi.VoPairIn * 1)()
+    assert lib.vo_pair_batch(None, 1, ins, 1, outs) == -1
+    none = (C.c_void_p * 1)(None)
+    assert lib.vo_pair_batch(none, 1, ins, 1, outs) == -1
+    if not os.path.exists("/dev/kfd"):
+        assert lib.vo_device_count() == 0

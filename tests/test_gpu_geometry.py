@@ -170,7 +170,12 @@ def test_essential_ransac_vs_oracle_solver(ctx, n, frac, noise, seed):
     else:
         assert (mask != rmask).mean() <= 2 * spread_mask + 1.0 / n
         assert _angle(Rg, Rr) <= 2 * spread_deg + 1e-6
-    assert _angle(Rg, Rr) < 0.1 or spread_deg > 0.05  # north star: pose vs the reference path within 0.1 degrees
+    # north star: pose vs the reference path within 0.1 degrees; where the oracle itself moves by more than 0.05 degrees under a
+    # 1-ulp change of K the bound is twice that spread, never more than 1 degree - and the case is printed, not silently accepted
+    bound = min(max(2 * spread_deg, 0.1), 1.0)
+    if bound > 0.1:
+        print(f"relaxed pose bound {bound:.3f} deg (oracle spread {spread_deg:.3f}) for n={n} frac={frac} noise={noise} seed={seed}: {_angle(Rg, Rr):.4f}")
+    assert _angle(Rg, Rr) <= bound
     assert _angle(Rg, R) < (1.0 if n >= 2000 else 10.0)  # sanity against the ground truth of the synthetic scene
 
 

@@ -59,7 +59,10 @@ def test_shortlist_scores_of_every_scanned_tile_are_settled(ctx):
                     worst = max(worst, abs(float(cv[q, 4 * g + k]) - S[q, rows].max()))
                     seen.add(bl >> 2)
     assert seen == set(range(7))  # every tile of the 200 train rows, first and last steps of each split
-    assert worst < 2e-5, worst  # 3 * 2^-16 * |a||b| = 4.6e-5 is the bound; observed 5e-6
+    # vo_match.hip kCertMargin = 2e-4 rests on |MFMA score - exact score| <= eps = 6.5e-5 for unit vectors (split 3 * 2^-16 =
+    # 4.6e-5, FP32 accumulation 1.7e-5, norm 2e-6); observed 5e-6.  Must stay below kCertMargin / 4 with room to spare.
+    K_CERT_MARGIN = 2e-4
+    assert worst < K_CERT_MARGIN / 4 and worst < 2e-5, worst
 
 
 def _redo_count(ctx):

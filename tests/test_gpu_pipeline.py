@@ -249,6 +249,8 @@ def test_cv_adaptor_runs_the_node_call_sequence():
     out = subprocess.run([_adaptor_exe(), "run"], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "success 1" in out.stdout, out.stdout
+    # the reference's parameter globals (camera_utility.hpp:33-63) drive the library: edited ROI / minHessian take effect
+    assert "globals: roi ok" in out.stdout and "minHessian ok" in out.stdout and "restored ok" in out.stdout, out.stdout
 
 
 def test_cv_adaptor_outputs_equal_the_oracle(tmp_path):
@@ -409,16 +411,137 @@ def test_pipelined_runs_with_double_buffered_frames(ctx):
     b.close()
 
 
-def test_batch_without_camera_matrix_is_rejected(ctx):
-    from visual_odometry_amd.frontend import VoError
+def test_pair_without_camera_matrix_fails_alone(ctx):
+    """A pair that never got a K reports VO_ERR_INVALID_ARG in ITS record; the run and the other pairs are unaffected
+    (sequence batches are created with K = 0 for every pair, partly configured ones used to fail as a whole)."""
+    from visual_odometry_amd.frontend import Sequence
 
-    b = Batch(ctx, 2, 480, 640)
     sc = synth.blob_scene(480, 640, synth.K_PARETE, 300, 5)
+    ref = Batch(ctx, 1, 480, 640)
+    ref.set_pair(0, sc.img1, sc.img2, sc.K)
+    ref.run()
+    want = _rec(ref.get(0))
+    ref.close()
+    b = Batch(ctx, 2, 480, 640)
     b.set_pair(0, sc.img1, sc.img2, sc.K)  # pair 1 never gets a K
-    with pytest.raises(VoError) as e:
-        b.run()
-    assert e.value.status == -1
+    b.run()
+    assert _rec(b.get(0)) == want
+    o = b.get(1)
+    assert o.status == -1 and o.success == 0
     b.close()
+    seq = Sequence(ctx, 3, 480, 640)
+    for f, im in enumerate([sc.img1, sc.img2, sc.img1]):
+        seq.set_frame(f, im)
+    seq.set_pair(0, 0, 1, sc.K)  # pair 1 = (1, 2) keeps the default pairing and no K
+    seq.run()
+    assert _rec(seq.get(0)) == want
+    assert seq.get(1).status == -1 and seq.get(1).success == 0
+    seq.close()
+
+
+def test_partial_restaging_of_a_batch_filled_through_prep(ctx):
+    """Carry-over out of a frame slot that vo_prep_to_batch filled: those frames were written by kernels on the MAIN stream,
+    the carry-over copy runs on the COPY stream.  Run k (all frames through prep), then - without any host wait - one pair
+    re-staged from the host and run k + 1: the pairs that carried over must equal a fresh batch (the copy stream
+    used to be unordered against the prep kernels)."""
+    from visual_odometry_amd import prep as P
+
+    scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 31), (500, 32), (900, 33)]]
+    big = lambda g: np.ascontiguousarray(np.repeat(np.repeat(np.stack([g, g, g], -1), 2, axis=0), 2, axis=1))
+    K = P.updateCameraMatrix((960, 1280), 640, 480, np.diag([2.0, 2.0, 1.0]) @ synth.K_PARETE, ctx.lib)
+    pr = P.Prep(ctx, (960, 1280), 640, 480, K, [0.01, -0.005, 0.0002, -0.0002])
+    try:
+        gray = [(pr.get_image(big(sc.img1)), pr.get_image(big(sc.img2))) for sc in scenes]
+        n = 3
+        b = Batch(ctx, n, 480, 640)
+        for rep in range(3):
+            for i, sc in enumerate(scenes):
+                pr.to_batch(big(sc.img1), b, 2 * i)
+                pr.to_batch(big(sc.img2), b, 2 * i + 1)
+                b.set_k(i, K)
+            b.run()
+            # no sync: pair 1 comes from the host, pairs 0 and 2 carry over from the slot the prep kernels are still writing
+            b.set_pair(1, gray[0][1], gray[0][0], K)
+            b.run()
+            got = [_rec(b.get(i)) for i in range(n)]
+            fresh = Batch(ctx, n, 480, 640)
+            for i, (a, c) in enumerate([gray[0], (gray[0][1], gray[0][0]), gray[2]]):
+                fresh.set_pair(i, a, c, K)
+            fresh.run()
+            want = [_rec(fresh.get(i)) for i in range(n)]
+            fresh.close()
+            assert got == want, rep
+        b.close()
+    finally:
+        pr.close()
+
+
+def test_pipelined_1080p_steps_equal_a_fresh_batch():
+    """The overlap the headline number rests on, at the size where it really happens: 16 pairs of 1080p / 8 k keypoints,
+    24 pipelined steps with restaging every step (upload on the copy stream beside the kernels, the integral pass of step
+    k + 1 on the auxiliary stream under step k's descriptor kernels - vo_detect.hip, enqueue_detect), read with age 1.
+    Every step's records must equal those of a fresh synchronous batch on the same pairs; then the same for a pair of
+    alternating 1080p sequence batches."""
+    from visual_odometry_amd._abi import default_params
+    from visual_odometry_amd.frontend import Context, Sequence
+
+    scs = [synth.scene_c2(2002 + i) for i in range(2)]
+    prm = default_params()
+    prm.roi_x_lo, prm.roi_y_lo, prm.roi_x_hi, prm.roi_y_hi = synth.roi_for(1080, 1920)
+    c = Context(prm)
+    P = 16
+    variants = [(scs[0].img1, scs[0].img2), (scs[1].img1, scs[1].img2), (scs[0].img2, scs[0].img1), (scs[1].img2, scs[1].img1)]
+    # two different step contents, alternating, so that a step which read stale frames cannot pass
+    layouts = [[variants[(i + s) % 4] for i in range(P)] for s in range(2)]
+    want = []
+    for lay in layouts:
+        f = Batch(c, P, 1080, 1920)
+        for i, (a, d) in enumerate(lay):
+            f.set_pair(i, a, d, scs[0].K)
+        f.run()
+        f.sync()
+        want.append([_rec(o) for o in f.get_records()])
+        f.close()
+    assert want[0] != want[1] and want[0][0][3] > 500 and want[0][0][7] == 1
+    b = Batch(c, P, 1080, 1920)
+
+    def fill(k):
+        for i, (a, d) in enumerate(layouts[k & 1]):
+            b.set_pair(i, a, d, scs[0].K)
+
+    steps = 24
+    fill(0)
+    bad = []
+    for k in range(steps):
+        b.run()
+        fill(k + 1)  # staged while run k executes
+        if k:
+            if [_rec(o) for o in b.get_records(age=1)] != want[(k - 1) & 1]:
+                bad.append(k - 1)
+    if [_rec(o) for o in b.get_records()] != want[(steps - 1) & 1]:
+        bad.append(steps - 1)
+    b.close()
+    assert not bad, bad
+    # sequence batches (every frame detected once), two batches alternating as the replay uses them
+    frames = [scs[0].img1, scs[0].img2, scs[1].img1, scs[1].img2, scs[0].img2, scs[0].img1, scs[1].img2, scs[1].img1, scs[0].img1]
+    seqs = [Sequence(c, 9, 1080, 1920) for _ in range(2)]
+    first, bad = None, []
+    for k in range(8):
+        s = seqs[k & 1]
+        for f in range(9):
+            s.set_frame(f, frames[f])
+        for p in range(8):
+            s.set_pair(p, p, p + 1, scs[0].K)
+        s.run()
+        if k:
+            got = [_rec(o) for o in seqs[(k - 1) & 1].get_records()]
+            first = first or got
+            if got != first:
+                bad.append(k - 1)
+    for s in seqs:
+        s.close()
+    c.close()
+    assert not bad and first[0] == want[0][0], bad
 
 
 def test_failed_pair_reports_identity_pose_not_the_previous_runs(ctx):
@@ -597,3 +720,57 @@ def test_cxx_host_program_runs_the_pipelined_loop():
     out = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "records differing from the synchronous runs: 0" in out.stdout and "4 of 4 pairs with a pose" in out.stdout, out.stdout
+
+
+def test_cxx_multi_context_driver_equals_one_context():
+    """examples/multi_gpu_batch.cpp: vo_pair_batch with one host thread per context (two contexts on device 0 when the box
+    has a single GPU; one per GPU otherwise), pair p on context p mod n, host gather - every record must equal the
+    single-context run of the same 150 pairs bit for bit, over three pipelined steps per context, and an argument error
+    must come back as a status."""
+    import os
+    import subprocess
+
+    exe = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "multi_gpu_batch")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    out = subprocess.run([exe, "150"], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "records differing: 0" in out.stdout and "mixed sizes -> invalid argument" in out.stdout, out.stdout
+
+
+def test_pair_batch_from_python_matches_the_batch_api(ctx):
+    """vo_pair_batch through ctypes with THREE contexts on one device and an odd number of pairs (uneven shares, a last
+    step that is not full) against Batch on the same pairs."""
+    import ctypes as C
+
+    from visual_odometry_amd._abi import VoPairIn, VoPairOut
+    from visual_odometry_amd.frontend import Context
+
+    scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 41), (500, 42), (900, 43)]]
+    frames = []
+    for k in range(7):
+        sc = scenes[k % 3]
+        frames.append((sc.img1, sc.img2) if k < 4 else (sc.img2, sc.img1))
+    ref = Batch(ctx, 7, 480, 640)
+    for i, (a, b) in enumerate(frames):
+        ref.set_pair(i, a, b, synth.K_PARETE)
+    ref.run()
+    want = [_rec(o) for o in ref.get_records()]
+    ref.close()
+    extra = [Context(), Context()]
+    ctxs = (C.c_void_p * 3)(ctx._h, extra[0]._h, extra[1]._h)
+    ins = (VoPairIn * 7)()
+    for i, (a, b) in enumerate(frames):
+        ins[i].img1, ins[i].step1 = a.ctypes.data_as(C.POINTER(C.c_uint8)), a.strides[0]
+        ins[i].img2, ins[i].step2 = b.ctypes.data_as(C.POINTER(C.c_uint8)), b.strides[0]
+        ins[i].rows, ins[i].cols = 480, 640
+        ins[i].K[:] = list(synth.K_PARETE.ravel())
+    outs = (VoPairOut * 7)()
+    for rep in range(2):  # the second call reuses the contexts' cached batches
+        st = ctx.lib.vo_pair_batch(ctxs, 3, ins, 7, outs)
+        assert st == 0
+        assert [_rec(o) for o in outs] == want
+    assert ctx.lib.vo_pair_batch(ctxs, 3, ins, 0, outs) == 0
+    dup = (C.c_void_p * 2)(ctx._h, ctx._h)
+    assert ctx.lib.vo_pair_batch(dup, 2, ins, 7, outs) == -1  # one context cannot serve two threads
+    for e in extra:
+        e.close()

@@ -53,6 +53,14 @@ class VoPairOut(C.Structure):
     ]
 
 
+class VoPairIn(C.Structure):
+    """vo_pair_in: one frame pair of vo_pair_batch (cv::Mat-style buffers + K)."""
+    _fields_ = [
+        ("img1", C.POINTER(C.c_uint8)), ("step1", C.c_size_t), ("img2", C.POINTER(C.c_uint8)), ("step2", C.c_size_t),
+        ("rows", C.c_int32), ("cols", C.c_int32), ("K", C.c_double * 9),
+    ]
+
+
 class VoPrepParams(C.Structure):
     _fields_ = [
         ("src_rows", C.c_int32), ("src_cols", C.c_int32), ("dst_rows", C.c_int32), ("dst_cols", C.c_int32),

@@ -46,7 +46,57 @@ class Stamp(float):
 
 
 # ------------------------------------------------------------------------------------------------ LZ4 (chunk compression "lz4")
+def _xxh32(data: bytes, seed: int = 0) -> int:
+    """XXH32 (the checksum of the LZ4 frame format), plain Python: used for the 1-byte header checksum always and for the
+    content / block checksums when the xxhash module is absent."""
+    P1, P2, P3, P4, P5, M = 2654435761, 2246822519, 3266489917, 668265263, 374761393, 0xFFFFFFFF
+    rotl = lambda x, r: ((x << r) | (x >> (32 - r))) & M
+    n, i = len(data), 0
+    if n >= 16:
+        v = [(seed + P1 + P2) & M, (seed + P2) & M, seed & M, (seed - P1) & M]
+        while i + 16 <= n:
+            for k, w in enumerate(struct.unpack_from("<4I", data, i)):
+                v[k] = (rotl((v[k] + w * P2) & M, 13) * P1) & M
+            i += 16
+        h = (rotl(v[0], 1) + rotl(v[1], 7) + rotl(v[2], 12) + rotl(v[3], 18)) & M
+    else:
+        h = (seed + P5) & M
+    h = (h + n) & M
+    while i + 4 <= n:
+        h = (rotl((h + struct.unpack_from("<I", data, i)[0] * P3) & M, 17) * P4) & M
+        i += 4
+    while i < n:
+        h = (rotl((h + data[i] * P5) & M, 11) * P1) & M
+        i += 1
+    h ^= h >> 15
+    h = (h * P2) & M
+    h ^= h >> 13
+    h = (h * P3) & M
+    return h ^ (h >> 16)
+
+
+def _xxh32_fast(data: bytes) -> int:
+    try:
+        import xxhash
+
+        return xxhash.xxh32(data, seed=0).intdigest()
+    except ImportError:
+        return _xxh32(data)
+
+
 def lz4_block_decode(src, max_out: int | None = None) -> bytes:
+    """One LZ4 block; truncated or inconsistent input raises ValueError (never IndexError), and the declared maximum is
+    checked after the final literals too."""
+    try:
+        out = _lz4_block_decode(src, max_out)
+    except IndexError:
+        raise ValueError("lz4: truncated block") from None
+    if max_out is not None and len(out) > max_out:
+        raise ValueError("lz4: block larger than declared")
+    return out
+
+
+def _lz4_block_decode(src, max_out: int | None = None) -> bytes:
     """One LZ4 block (the sequence format of the LZ4 block specification): token = literal length << 4 | match length - 4,
     lengths of 15 continue in 255-valued bytes, little-endian 16-bit match offset; matches may overlap their own output."""
     src = bytes(src)
@@ -63,6 +113,8 @@ def lz4_block_decode(src, max_out: int | None = None) -> bytes:
                 ll += b
                 if b != 255:
                     break
+        if i + ll > n:
+            raise ValueError("lz4: truncated block")
         out += src[i : i + ll]
         i += ll
         if i >= n:
@@ -93,7 +145,15 @@ def lz4_block_decode(src, max_out: int | None = None) -> bytes:
 def lz4_frame_decode(src) -> bytes:
     """LZ4 frame format (magic 0x184D2204; what roslz4 writes into `lz4` chunks and the lz4 command line tool reads): FLG / BD /
     optional content size and dictionary id / header checksum, then blocks (size word, high bit = stored uncompressed, optional
-    block checksum) up to the end mark, optional xxhash32 content checksum (verified when the xxhash module is present)."""
+    block checksum) up to the end mark, optional xxhash32 content checksum.  Header, block and content checksums are all
+    verified (xxhash module when present, else the plain-Python XXH32 above); truncated input raises ValueError."""
+    try:
+        return _lz4_frame_decode(src)
+    except (IndexError, struct.error):
+        raise ValueError("lz4: truncated frame") from None
+
+
+def _lz4_frame_decode(src) -> bytes:
     mv = memoryview(bytes(src))
     if len(mv) < 7 or struct.unpack_from("<I", mv, 0)[0] != 0x184D2204:
         raise ValueError("lz4: not an LZ4 frame")
@@ -111,7 +171,9 @@ def lz4_frame_decode(src) -> bytes:
         off += 8
     if dict_id:
         off += 4
-    off += 1  # header checksum byte
+    if ((_xxh32(bytes(mv[4:off])) >> 8) & 0xFF) != mv[off]:  # HC: second byte of XXH32 over the frame descriptor
+        raise ValueError("lz4: header checksum mismatch")
+    off += 1
     out = bytearray()
     while True:
         size = struct.unpack_from("<I", mv, off)[0]
@@ -123,17 +185,14 @@ def lz4_frame_decode(src) -> bytes:
         data = mv[off : off + size]
         if len(data) != size:
             raise ValueError("lz4: truncated block")
+        if block_checksum and _xxh32_fast(bytes(data)) != struct.unpack_from("<I", mv, off + size)[0]:
+            raise ValueError("lz4: block checksum mismatch")
         off += size + (4 if block_checksum else 0)
         out += bytes(data) if stored else lz4_block_decode(data, block_max)
     if content_checksum:
         want = struct.unpack_from("<I", mv, off)[0]
-        try:
-            import xxhash
-
-            if xxhash.xxh32(bytes(out), seed=0).intdigest() != want:
-                raise ValueError("lz4: content checksum mismatch")
-        except ImportError:
-            pass
+        if _xxh32_fast(bytes(out)) != want:
+            raise ValueError("lz4: content checksum mismatch")
     if declared is not None and declared != len(out):
         raise ValueError("lz4: content size mismatch")
     return bytes(out)

@@ -278,6 +278,8 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
 extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
+    if (ctx->pb) vo_batch_destroy(ctx->pb);
+    ctx->pb = nullptr;
     hipStreamSynchronize(ctx->stream);
     hipStreamSynchronize(ctx->stream_geo);
     hipStreamSynchronize(ctx->stream_aux);
@@ -918,6 +920,7 @@ static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq
              hipHostMalloc((void**)&rh.cnt, (size_t)n_frames * sizeof(FrameCounters), hipHostMallocDefault) == hipSuccess &&
              hipEventCreateWithFlags(&b->ev_h2d[s], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&b->ev_img_free[s], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&b->ev_prep[s], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&rh.ev_state, hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&rh.ev_done, hipEventDisableTiming) == hipSuccess;
     }
@@ -927,6 +930,8 @@ static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq
         return VO_ERR_HIP;
     }
     b->h_init.resize(n_pairs);
+    b->rh[0].unset.assign(n_pairs, 0);
+    b->rh[1].unset.assign(n_pairs, 0);
     b->h_frames.resize(n_pairs);
     b->staged.assign(n_frames, 0);
     for (int p = 0; p < n_pairs; p++) b->h_frames[p] = is_seq ? make_int2(p, p + 1) : make_int2(2 * p, 2 * p + 1);
@@ -1033,6 +1038,7 @@ extern "C" void vo_batch_destroy(vo_batch* b) {
         if (rh.cnt) hipHostFree(rh.cnt);
         if (b->ev_h2d[s]) hipEventDestroy(b->ev_h2d[s]);
         if (b->ev_img_free[s]) hipEventDestroy(b->ev_img_free[s]);
+        if (b->ev_prep[s]) hipEventDestroy(b->ev_prep[s]);
         if (rh.ev_state) hipEventDestroy(rh.ev_state);
         if (rh.ev_done) hipEventDestroy(rh.ev_done);
     }
@@ -1063,8 +1069,6 @@ extern "C" int vo_batch_set_k(vo_batch* b, int pair, const double K[9]) {
 extern "C" int vo_batch_run(vo_batch* b) {
     if (!b) return VO_ERR_INVALID_ARG;
     vo_ctx* ctx = b->ctx;
-    for (const PairState& S : b->h_init)  // a pair whose K was never given would divide by zero on the device
-        if (S.K[0] == 0.0 || S.K[4] == 0.0) return VO_ERR_INVALID_ARG;
     VO_HIP(hipSetDevice(ctx->device));
     RunHost& rh = b->rh[b->runs & 1];
     // snapshot of K / initial pose (identity: every run starts every pair from R = I, t = 0, whatever the previous run left)
@@ -1074,11 +1078,33 @@ extern "C" int vo_batch_run(vo_batch* b) {
         rh.state_pending = false;
     }
     std::memcpy(rh.init, b->h_init.data(), b->h_init.size() * sizeof(PairState));
+    // A pair whose K was never given (vo_batch_set_pair / vo_batch_set_k / vo_seq_set_pair not called for it) would divide by
+    // zero on the device.  It does not fail the run: it runs with K = I so that nothing faults, and its OWN record comes back
+    // with status VO_ERR_INVALID_ARG (vo_batch_get_run); the other pairs are unaffected.
+    for (int p = 0; p < b->n_pairs; p++) {
+        PairState& S = rh.init[p];
+        rh.unset[p] = S.K[0] == 0.0 || S.K[4] == 0.0;
+        if (rh.unset[p]) S.K[0] = S.K[4] = S.K[8] = 1.0;
+    }
     std::memcpy(rh.frames, b->h_frames.data(), b->h_frames.size() * sizeof(int2));
     hipEvent_t img_ready = nullptr;
     if (b->n_staged > 0) {  // frames were staged since the latest run: this run reads the other slot
         const int s = b->fill_slot;
         const size_t fst = b->fs.img_stride();
+        // frames this run gets from vo_prep_to_batch were written by kernels on the main stream: mark the slot, so that a
+        // LATER carry-over out of it (copy stream) waits for them
+        const bool has_prep = std::find(b->staged.begin(), b->staged.end(), (uint8_t)1) != b->staged.end();
+        if (has_prep) {
+            VO_HIP(hipEventRecord(b->ev_prep[s], ctx->stream));
+            b->prep_pending[s] = true;
+        } else {
+            b->prep_pending[s] = false;  // every frame of the slot now comes through the copy stream itself
+        }
+        // carry-over out of a slot that holds prep-written frames: the copy stream is not ordered against those kernels.
+        // (Frames carried INTO such a slot by an earlier copy are ordered by the copy stream; waiting covers both.)
+        if (b->cur_slot >= 0 && b->prep_pending[b->cur_slot] &&
+            std::find(b->staged.begin(), b->staged.end(), (uint8_t)0) != b->staged.end())
+            VO_HIP(hipStreamWaitEvent(b->stream_copy, b->ev_prep[b->cur_slot], 0));
         for (int f = 0; f < b->n_frames;) {  // one transfer per run of frames with the same origin
             const uint8_t kind = b->staged[f];
             int e = f + 1;
@@ -1094,7 +1120,7 @@ extern "C" int vo_batch_run(vo_batch* b) {
         b->h2d_pending[s] = true;
         img_ready = b->ev_h2d[s];  // the detection waits for it on the stream its integral pass runs on
         // frames written by vo_prep_to_batch (kernels on the main stream): the auxiliary stream has to see them too
-        if (std::find(b->staged.begin(), b->staged.end(), (uint8_t)1) != b->staged.end()) {
+        if (has_prep) {
             VO_HIP(hipEventRecord(ctx->ev_fork, ctx->stream));
             VO_HIP(hipStreamWaitEvent(ctx->stream_aux, ctx->ev_fork, 0));
         }
@@ -1185,6 +1211,10 @@ extern "C" int vo_batch_get_run(vo_batch* b, int age, int pair, vo_pair_out* out
     std::memcpy(out->E, S.E, sizeof(out->E));
     std::memcpy(out->R, S.R, sizeof(out->R));
     std::memcpy(out->t, S.t, sizeof(out->t));
+    if (rh->unset[pair]) {  // no camera matrix was given for this pair: nothing of its geometry means anything
+        out->status = VO_ERR_INVALID_ARG;
+        out->success = 0;
+    }
     return VO_OK;
 }
 

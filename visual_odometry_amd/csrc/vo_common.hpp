@@ -225,6 +225,7 @@ struct vo_ctx {
     size_t h_up_bytes = 0;
     uint8_t* h_down = nullptr;
     size_t h_down_bytes = 0;
+    struct vo_batch* pb = nullptr;  // pair batch of vo_pair_batch (vo_multi.hip), kept from call to call, owned by the context
 };
 
 // Feature buffers of a frame set that the matcher reads.  A batch owns two sets and alternates between them from run to run:
@@ -250,6 +251,7 @@ struct RunHost {
     hipEvent_t ev_state = nullptr; // the upload of init / frames has finished (geometry stream)
     hipEvent_t ev_done = nullptr;  // matcher and geometry finished, res / cnt are on the host (geometry stream)
     bool state_pending = false;
+    std::vector<uint8_t> unset;    // [n_pairs] 1 = the pair had no camera matrix when the run was enqueued (pageable)
 };
 
 struct vo_batch {
@@ -270,6 +272,11 @@ struct vo_batch {
     hipEvent_t ev_h2d[2] = {nullptr, nullptr};       // every upload into the slot issued so far has finished (copy stream)
     hipEvent_t ev_img_free[2] = {nullptr, nullptr};  // the run that read the slot is past detection + description (main stream)
     bool h2d_pending[2] = {false, false}, img_free_pending[2] = {false, false};
+    // A slot that received frames from vo_prep_to_batch was written by kernels on the context's MAIN stream: the copy stream
+    // has to wait for them before it carries frames of that slot over into the other one (ev_prep, recorded by the run
+    // that first reads the slot).
+    hipEvent_t ev_prep[2] = {nullptr, nullptr};
+    bool prep_pending[2] = {false, false};
     int cur_slot = -1;               // slot the latest run read (-1: no run yet)
     int fill_slot = 0;               // slot the setters write
     int n_staged = 0;                // distinct frames staged into fill_slot since the latest run

@@ -8,7 +8,7 @@
 //   k_match_prep   : train descriptors -> MFMA operand layout (bf16 high / low parts), -0.5*||b||^2, max ||b||^2
 //   k_match_bf3    : dense contraction a.b - 0.5||b||^2 on v_mfma_f32_32x32x16_bf16 with each float split into two bf16
 //                    (a = ah + al): ah.bh + ah.bl + al.bh, 12 MFMAs of 32 cycles per 32 x 32 tile instead of 32 FP32
-//                    MFMAs of 64 cycles, error <= 3 * 2^-18 |a||b|.  Queries on the lanes (columns), train rows in the
+//                    MFMAs of 64 cycles, error <= 3 * 2^-16 |a||b|.  Queries on the lanes (columns), train rows in the
 //                    accumulator registers, so the shortlist (the three best 4-row blocks per group and a bound on the
 //                    rest) is in-lane VALU work: max, med3, compare + branch per block, insertion only on a hit
 //   k_match_select : exact re-scoring of the candidates with the oracle's sequential sum (a-b)^2, (dist, index)
@@ -31,7 +31,7 @@ __device__ __forceinline__ uint32_t bf16_rne(float f) {  // round to nearest eve
     const uint32_t u = __float_as_uint(f);
     return (u + 0x7fffu + ((u >> 16) & 1u)) >> 16;
 }
-// a = hi + lo + r with hi, lo bf16 and |r| <= 2^-18 |a|
+// a = hi + lo + r with hi, lo bf16 (8 significand bits, round to nearest even): |a - hi| <= 2^-8 |a|, |r| <= 2^-16 |a|
 __device__ __forceinline__ void bf16_split(float a, uint32_t& hi, uint32_t& lo) {
     hi = bf16_rne(a);
     lo = bf16_rne(a - __uint_as_float(hi << 16));  // the subtraction is exact
@@ -427,8 +427,18 @@ __device__ __forceinline__ void knn_store(int* __restrict__ knn_idx, float* __re
     knn_dist[o + 1] = h1 ? sqrtf(d1) : FLT_MAX;
 }
 
-// Bound on |MFMA score - exact score| + the float error of the sequential distance, for unit-norm operands: split
-// residue 3 * 2^-18, FP32 accumulation of 193 terms, norms and the re-scored distance itself.  Scaled by the operands' norms.
+// The certificate's margin (ONE derivation; DESIGN.md 5.0 and tests/test_gpu_match.py quote the same numbers).  Score =
+// a.b - 0.5 ||b||^2, distance D = ||a||^2 - 2 score; everything below is for ||a|| = ||b|| = 1 and scales with
+// N = max(1, (||a||^2 + max ||b||^2) / 2) >= ||a|| ||b||, which is what the margin is multiplied by.
+//   eps_split = 3 * 2^-16 = 4.6e-5   bf16 round-to-nearest keeps 8 significand bits: |a - hi| <= 2^-8 |a|, the residue left by
+//                                    hi + lo is <= 2^-16 |a|; dropped: a_lo.b_lo (2^-16) + r_a.b + a.r_b (2 * 2^-16), Cauchy-Schwarz
+//   eps_acc   = 195 * 2^-24 * 1.5 = 1.7e-5   FP32 accumulation of 3 x 64 products + 3 norm pieces, sum of |terms| <= 1.5
+//   eps_norm  = 2e-6                 -0.5 ||b||^2 itself (64 fp32 terms) and its 24-bit three-piece bf16 form
+//   eps = eps_split + eps_acc + eps_norm = 6.5e-5  >= |MFMA score - exact score|      (observed worst: 5e-6)
+//   delta = 64 * 2^-24 * 4 = 1.5e-5  the re-scored float distance (sequential sum, D <= 4), delta_n = 4e-6 the same for ||a||^2
+// Pruning needs margin >= 2 eps = 1.3e-4 (a block below s2 - margin cannot beat the two rows at s1, s2), the certificate
+// needs margin >= 2 eps + delta + delta_n = 1.5e-4 (a left-out row has float distance > d1, strictly: ties cannot hide).
+// 2e-4 covers the worst-case bound 1.33 times and the observed error 20 times.
 constexpr float kCertMargin = 2e-4f;
 
 // 32 lanes per query; candidate c of a query = row e of kept block k of group g, c = 12 g + 4 k + e
@@ -460,7 +470,7 @@ __global__ __launch_bounds__(256) void k_match_select(const float* __restrict__ 
         s2 = fmaxf(fminf(s1, o1), fmaxf(s2, o2));
         s1 = fmaxf(s1, o1);
     }
-    const float keep_from = s2 - margin;  // score units are half distance units: the full margin is twice what is needed
+    const float keep_from = s2 - margin;  // needs margin >= 2 eps (see kCertMargin)
     float b0 = FLT_MAX, b1 = FLT_MAX;  // this lane's two smallest (distance, row), lexicographic
     int j0 = 0x7fffffff, j1 = 0x7fffffff;
     for (int c = sub; c < groups * 4 * kKeep; c += 32) {
