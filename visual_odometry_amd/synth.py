@@ -160,8 +160,9 @@ def surf_like_descriptors(n: int, seed: int) -> np.ndarray:
 
 # ---- named workloads of BASELINE.json / SURVEY.md 8d -------------------------------------------------------
 def scene_c1(seed: int = 1001) -> Scene:
-    """C1: Parete-like 640x480 pair, ~1k-2k keypoints, camera_intrinsic.yaml intrinsics."""
-    return blob_scene(480, 640, K_PARETE, 500, seed)
+    """C1: Parete-like 640x480 pair, ~2k keypoints per frame (BASELINE configs[0]) and 500-900 matches,
+    camera_intrinsic.yaml intrinsics."""
+    return blob_scene(480, 640, K_PARETE, 1400, seed, depth=(6.0, 9.0))
 
 
 def scene_c2(seed: int = 2002) -> Scene:
