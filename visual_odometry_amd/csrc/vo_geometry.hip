@@ -27,12 +27,28 @@
 // ------------------------------------------------------------------------------------------------
 // small device helpers
 // ------------------------------------------------------------------------------------------------
-__device__ __forceinline__ double sum16(double v) {  // sum over an aligned 16-lane group
-    v += __shfl_xor(v, 8, 16);
-    v += __shfl_xor(v, 4, 16);
-    v += __shfl_xor(v, 2, 16);
-    v += __shfl_xor(v, 1, 16);
+// lane k <- lane (k + N) mod 16 of its aligned 16-lane row: one DPP move per 32-bit half (no LDS crossbar round trip)
+template <int N>
+__device__ __forceinline__ double row_ror(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + N, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + N, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+// Sum over an aligned 16-lane group, the same in every lane.  Butterfly k ^ 8, k ^ 4, k ^ 2, k ^ 1 written as row rotations:
+// after the step with distance d the values have period d, so lane (k + d/2) mod 16 holds what lane k ^ (d/2) holds - the
+// operands of every add are those of the xor butterfly (bit-identical, additions commute).
+__device__ __forceinline__ double sum16(double v) {
+    v += row_ror<8>(v);
+    v += row_ror<4>(v);
+    v += row_ror<2>(v);
+    v += row_ror<1>(v);
     return v;
+}
+// value of lane `src` (compile-time constant after unrolling) in every lane: two v_readlane, result in scalar registers
+__device__ __forceinline__ double lane_bcast(double v, int src) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
 }
 
 // One-sided Jacobi SVD of the rows of At (OpenCV JacobiSVDImpl_<double>), N <= 4,
@@ -164,6 +180,26 @@ __device__ __forceinline__ float sampson_err(const double E[9], double ax, doubl
     const double x2tEx1 = bx * Ex0 + by * Ex1 + 1. * Ex2;
     const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
     return (float)(x2tEx1 * x2tEx1 / (a + b + c + d));
+}
+
+// findInliers' test (float)(n^2 / d) <= thr for one point WITHOUT the division in all but the rare borderline case: with
+// T = (double)thr, n^2 <= T (1 - 1e-6) d puts the quotient a millionth below T (the float rounding moves it by 6e-8 at most, the
+// double division by 1e-16), n^2 >= T (1 + 1e-6) d a millionth above it; only a point inside that band - or a degenerate
+// d = 0, where the reference compares a NaN or an infinity - takes the division.  Same verdict as sampson_err(...) <= thr.
+__device__ __forceinline__ bool sampson_inlier(const double E[9], double ax, double ay, double bx, double by, float thr,
+                                               double thr_lo, double thr_hi) {
+    const double Ex0 = E[0] * ax + E[1] * ay + E[2] * 1.;
+    const double Ex1 = E[3] * ax + E[4] * ay + E[5] * 1.;
+    const double Ex2 = E[6] * ax + E[7] * ay + E[8] * 1.;
+    const double Et0 = E[0] * bx + E[3] * by + E[6] * 1.;
+    const double Et1 = E[1] * bx + E[4] * by + E[7] * 1.;
+    const double x2tEx1 = bx * Ex0 + by * Ex1 + 1. * Ex2;
+    const double a = Ex0 * Ex0, b = Ex1 * Ex1, c = Et0 * Et0, d = Et1 * Et1;
+    const double num = x2tEx1 * x2tEx1, den = a + b + c + d;
+    const bool sure_in = num <= thr_lo * den && den > 0, sure_out = num >= thr_hi * den && den > 0;
+    bool in = sure_in;
+    if (!(sure_in || sure_out)) in = (float)(num / den) <= thr;
+    return in;
 }
 
 __device__ int d_ransac_update_num_iters(double p, double ep, int modelPoints, int maxIters) {
@@ -323,15 +359,26 @@ struct HypShared {
     double b[3][13];
     double term[3][11];
     double c[11];
-    double rre[10], rim[10];
     double E[kMaxModels][9];
     double zroot[10];
     int valid[10];
+    int cnt[kMaxModels];
     int piv;
     int nm;
 };
 
-__global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1_base, const double* __restrict__ m2_base,
+#ifdef VO_RANSAC_TIMING
+__device__ unsigned long long g_rt[16];
+#define RT_MARK(i) do { if (lane == 0) { const unsigned long long t_ = wall_clock64(); atomicAdd(&g_rt[i], t_ - rt_prev); rt_prev = t_; } } while (0)
+extern "C" int vo_debug_ransac_timing(unsigned long long* out, int reset) {
+    if (out) hipMemcpyFromSymbol(out, HIP_SYMBOL(g_rt), sizeof(g_rt));
+    if (reset) { unsigned long long z[16] = {}; hipMemcpyToSymbol(HIP_SYMBOL(g_rt), z, sizeof(z)); }
+    return 0;
+}
+#else
+#define RT_MARK(i)
+#endif
+__global__ __launch_bounds__(64) __attribute__((amdgpu_waves_per_eu(4, 8))) void k_ransac_hyp(const double* __restrict__ m1_base, const double* __restrict__ m2_base,
                                                    int match_cap, const int* __restrict__ tuples_base, int max_hyp,
                                                    int h0, int h1, const PairState* __restrict__ st, const int* __restrict__ signs,
                                                    double* __restrict__ models_base, int* __restrict__ nmodels_base,
@@ -354,6 +401,10 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1
     double* models = models_base + ((size_t)pair * max_hyp + h) * kMaxModels * 9;
     int* counts = counts_base ? counts_base + ((size_t)pair * max_hyp + h) * kMaxModels : nullptr;
 
+#ifdef VO_RANSAC_TIMING
+    unsigned long long rt_prev = wall_clock64(), rt_iters = 0;
+    if (lane == 0) atomicAdd(&g_rt[15], 1ull);
+#endif
     // ---------------------------------------------------------------- (a) Q (5x9), lanes 0..8 hold column k
     const int k = lane & 15;  // column index within the 16-lane group; all four groups do the same work
     double a[9];              // a[i] = At[i][k]
@@ -407,6 +458,7 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1
         for (int v = 0; v < 4; v++) sh.Elin[lane][v] = a[5 + v];  // E = x E1 + y E2 + z E3 + E4
     }
     __syncthreads();
+    RT_MARK(0);
 
     // ---------------------------------------------------------------- (c) constraint polynomials
     // F = 2 E E^T - tr(E E^T) I  (symmetric, quadratic entries); lanes 0..5 each build one EEt entry
@@ -507,6 +559,7 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1
         }
     }
     __syncthreads();
+    RT_MARK(1);
 
     // ---------------------------------------------------------------- (d) Gauss-Jordan, partial pivoting
     bool singular = false;
@@ -554,6 +607,7 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1
         return;
     }
 
+    RT_MARK(2);
     // ---------------------------------------------------------------- (e) B(z) and its determinant
     if (lane < 3) {
         const double* ar1 = &sh.A[4 + 2 * lane][10];
@@ -658,38 +712,40 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1
     }
     __syncthreads();
 
+    RT_MARK(3);
     // ---------------------------------------------------------------- (f) roots: Durand-Kerner, lane per root
+    // The roots live in registers (lane j holds root j) and reach the other lanes through v_readlane; the coefficients are
+    // the same in every lane.  One iteration is a single pass with no LDS traffic and no barrier (it used to be two barriers
+    // and 2 * deg LDS reads per lane: 1.4 us per iteration, 60 % of a hypothesis).  Every lane reads the OLD roots of all
+    // lanes before any is updated, and the operations and their order are unchanged, so the roots are bit for bit the same.
     int deg = 10;
     for (; deg > 1; deg--)
         if (fabs(sh.c[deg]) > DBL_EPSILON) break;
-    {
-        // start values (1+i)^lane as in cv::solvePoly
-        double pr = 1, pi = 0;
-        for (int q = 0; q < lane && q < 10; q++) {
-            const double nr = pr * 1 - pi * 1, ni = pr * 1 + pi * 1;
-            pr = nr;
-            pi = ni;
-        }
-        if (lane < 10) {
-            sh.rre[lane] = pr;
-            sh.rim[lane] = pi;
-        }
+    double cf[10];  // cf[j] = c[deg - j - 1]: the coefficient Horner's step j adds
+#pragma unroll
+    for (int j = 0; j < 10; j++) cf[j] = lane_bcast(sh.c[max(deg - j - 1, 0)], 0);  // uniform: scalar registers
+    const double cdeg = lane_bcast(sh.c[deg], 0);
+    double pr = 1, pi = 0;  // start values (1+i)^lane as in cv::solvePoly
+    for (int q = 0; q < lane && q < 10; q++) {
+        const double nr = pr * 1 - pi * 1, ni = pr * 1 + pi * 1;
+        pr = nr;
+        pi = ni;
     }
-    __syncthreads();
     for (int iter = 0; iter < 300; iter++) {
-        double nre = 0, nim = 0, mre = 0, mim = 0;
+        double mre = pr, mim = pi;
         bool moving = false;
-        if (lane < deg) {
-            const double pr = sh.rre[lane], pi = sh.rim[lane];
-            double numr = sh.c[deg], numi = 0, denr = sh.c[deg], deni = 0;
-            for (int j = 0; j < deg; j++) {
+        double numr = cdeg, numi = 0, denr = cdeg, deni = 0;
+#pragma unroll
+        for (int j = 0; j < 10; j++) {
+            if (j < deg) {  // uniform
+                const double rjr = lane_bcast(pr, j), rji = lane_bcast(pi, j);
                 // num = num*p + c[deg-j-1]
-                const double tr = numr * pr - numi * pi + sh.c[deg - j - 1];
+                const double tr = numr * pr - numi * pi + cf[j];
                 const double ti = numr * pi + numi * pr;
                 numr = tr;
                 numi = ti;
                 if (j != lane) {
-                    const double dr = pr - sh.rre[j], di = pi - sh.rim[j];
+                    const double dr = pr - rjr, di = pi - rji;
                     if (dr != 0 || di != 0) {
                         const double er = denr * dr - deni * di, ei = denr * di + deni * dr;
                         denr = er;
@@ -697,31 +753,36 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1
                     }
                 }
             }
+        }
+        if (lane < deg) {
             const double t = 1. / (denr * denr + deni * deni);
-            nre = (numr * denr + numi * deni) * t;
-            nim = (-numr * deni + numi * denr) * t;
+            const double nre = (numr * denr + numi * deni) * t;
+            const double nim = (-numr * deni + numi * denr) * t;
             mre = pr - nre;
             mim = pi - nim;
             const double mag = fabs(nre) + fabs(nim);
             moving = mag > 1e-15 * (1.0 + fabs(pr) + fabs(pi));
         }
-        __syncthreads();
-        if (lane < deg) {
-            sh.rre[lane] = mre;
-            sh.rim[lane] = mim;
-        }
+        pr = mre;
+        pi = mim;
         const bool any = __ballot(moving) != 0ull;
-        __syncthreads();
+#ifdef VO_RANSAC_TIMING
+        rt_iters++;
+#endif
         if (!any) break;
     }
+#ifdef VO_RANSAC_TIMING
+    if (lane == 0) atomicAdd(&g_rt[14], rt_iters);
+#endif
+    RT_MARK(4);
 
     // ---------------------------------------------------------------- (g) back-substitution, lane per root
     bool ok = false;
     double Ev[9];
     double z1 = 0;
     if (lane < deg) {
-        z1 = sh.rre[lane];
-        const double zi = sh.rim[lane];
+        z1 = pr;
+        const double zi = pi;
         if (!(fabs(zi) > 1e-10)) {
             const double z2 = z1 * z1, z3 = z2 * z1, z4 = z3 * z1;
             double Bt[3][3], W[3], V[3][3];
@@ -770,24 +831,43 @@ __global__ __launch_bounds__(64) void k_ransac_hyp(const double* __restrict__ m1
     if (lane == 0) nmodels_base[(size_t)pair * max_hyp + h] = nm;
     __syncthreads();
 
+    RT_MARK(5);
     // ---------------------------------------------------------------- (h) Sampson scoring, lanes over points
     if (!counts) return;
-    for (int m = 0; m < nm; m++) {
-        double E[9];
-#pragma unroll
-        for (int e = 0; e < 9; e++) E[e] = sh.E[m][e];
-        int cnt = 0;
-        for (int base = 0; base < n; base += 64) {
-            const int i = base + lane;
-            bool in = false;
-            if (i < n) {
-                const double ax = m1[2 * i], ay = m1[2 * i + 1], bx = m2[2 * i], by = m2[2 * i + 1];
-                in = sampson_err(E, ax, ay, bx, by) <= thr_sq;
-            }
-            cnt += __popcll(__ballot(in));
-        }
-        if (lane == 0) counts[m] = cnt;
+    // Every point is loaded ONCE and tested against all candidate models (it used to be loaded once per model, and a
+    // wavefront waited out the latency of its four loads in every one of n / 64 x nm trips: 0.5 ms for 8192 matches); the
+    // loads of the next 64 points are in flight while the current ones are scored.  Counts are wavefront ballots in scalar
+    // registers.  Same sampson_err, same comparison: the counts are unchanged.
+    if (lane < kMaxModels) sh.cnt[lane] = 0;
+    __syncthreads();
+    const double thr_lo = (double)thr_sq * (1.0 - 1e-6), thr_hi = (double)thr_sq * (1.0 + 1e-6);
+    const double2* __restrict__ q1 = reinterpret_cast<const double2*>(m1);
+    const double2* __restrict__ q2 = reinterpret_cast<const double2*>(m2);
+    double2 na = make_double2(0, 0), nb = make_double2(0, 0);
+    if (lane < n) {
+        na = q1[lane];
+        nb = q2[lane];
     }
+    for (int base = 0; base < n; base += 64) {
+        const double2 pa = na, pb = nb;
+        const int i = base + lane, inext = i + 64;
+        if (inext < n) {
+            na = q1[inext];
+            nb = q2[inext];
+        }
+#pragma unroll 1
+        for (int m = 0; m < nm; m++) {  // a real loop: ten unrolled copies cost 80 more registers and a wavefront per SIMD
+            double E[9];
+#pragma unroll
+            for (int e = 0; e < 9; e++) E[e] = sh.E[m][e];
+            const bool in = i < n && sampson_inlier(E, pa.x, pa.y, pb.x, pb.y, thr_sq, thr_lo, thr_hi);
+            const int c = __popcll(__ballot(in));
+            if (lane == 0) atomicAdd(&sh.cnt[m], c);  // LDS add without return: nothing waits for it
+        }
+    }
+    __syncthreads();
+    if (lane < nm) counts[lane] = sh.cnt[lane];
+    RT_MARK(6);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1444,8 +1524,11 @@ int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o, hipStream
         // beside off the SIMDs (0.5 ms of a 35 ms step), although the adaptive bound is usually reached within a few
         // hypotheses.  Batches therefore start with 16; a single pair keeps 64 (its chunk is small, and a chunk more is 0.8 ms
         // of latency when the first one does not suffice).
-        const int bounds[7] = {0, P >= 8 ? 16 : 64, 64, 256, 1024, 2048, 4096};
-        for (int c = 0; c < 6; c++) {
+        // Past 256 hypotheses everything that is left goes out as ONE launch: a chunk costs a wavefront's lifetime (~0.1 - 0.3 ms)
+        // whatever its size, and wavefronts past the bound the scans have reached by then leave at once.  (If the bound drops
+        // inside that chunk the hypotheses behind it were solved for nothing; the in-order scan ignores them.)
+        const int bounds[5] = {0, P >= 8 ? 16 : 64, 64, 256, kMaxHyp};
+        for (int c = 0; c < 4; c++) {
             const int h0 = bounds[c], h1 = std::min(bounds[c + 1], o.max_iters);
             if (h0 >= h1) continue;  // an empty chunk (a single pair's second bound) or past max_iters
             {
