@@ -31,6 +31,7 @@ FP64_VALU_PEAK_TFLOPS = 78.6  # vector FP64 (MI355X_MICROARCH.md)
 N_SIMD, VALU_CLOCK_HZ = 1024, 2.4e9
 SAMPLE_ISSUE_CYCLES = 86  # VALU issue cycles of one bilinear window sample per wavefront
 MFMA_EXEC_FACTOR = 25.0 / 8.0  # executed bf16 MFMA flop per algorithmic FP32 flop of the matcher (split-bf16 products + norm step)
+C3_STEP_M, C3_DEPTH_M, C3_RELIEF_M = 0.5, 6.0, 1.8  # the configs[2] stand-in scene (synth.sequence_c3)
 TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")  # PMC passes of `bench.py --profile-region`
 
 
@@ -106,7 +107,9 @@ def make_inputs(args, rank, world, extras):
     c1 = res[args.scenes :]
     c3 = None
     if args.c3_frames >= 8 and not args.profile_region:
-        c3 = synth.sequence_c3(args.c3_frames, seed=3003, workers=workers)
+        # 0.5 m per frame over a seabed at 6 +- 1.8 m: ~48 px of image motion and enough relief for the cheirality gate
+        # (the gentler default scene of the tests - 0.36 m, 7 +- 1.2 m - sends 16 % of the pairs down the FAIL_RECOVER branch)
+        c3 = synth.sequence_c3(args.c3_frames, seed=3003, step_m=C3_STEP_M, depth=C3_DEPTH_M, relief=C3_RELIEF_M, workers=workers)
     return c2, c1, c3, workers, time.perf_counter() - t0
 
 
@@ -247,7 +250,7 @@ def main():
 
         ctx3 = Context(dp(), device=dev)  # the reference's own ROI (28/20/614/482) is the one for 640 x 505 frames
         n3 = len(c3.frames)
-        stamps, alt = 0.1 * np.arange(n3), np.full(n3, 7.0)
+        stamps, alt = 0.1 * np.arange(n3), np.full(n3, C3_DEPTH_M)
         stats = {}
         # warm-up: the same replay once (the context keeps its sequence / pair batches, so the timed run allocates nothing)
         replay.replay_sharded(ctx3, c3.frames, stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev)
@@ -260,7 +263,8 @@ def main():
         last = [r for r in recs if "estimate_pos" in r][-1]  # the last iteration that produced a pose (a stationary tail publishes none)
         c_true = -c3.Rw[last["frame"]].T @ c3.tw[last["frame"]]
         c3_out = {"value": round((n3 - 1) / d3, 2), "unit": "frames/s (one loop iteration of the node per frame)", "frames": n3, "size": "640x505",
-                  "K": "config/rapallo_intrinsic.yaml via updateCameraMatrix", "ranks": world, "seconds": round(d3, 4),
+                  "K": "config/rapallo_intrinsic.yaml via updateCameraMatrix", "ranks": world,
+                  "scene": {"step_m": C3_STEP_M, "depth_m": C3_DEPTH_M, "relief_m": C3_RELIEF_M, "stationary_frames": 25}, "seconds": round(d3, 4),
                   "success": fails.count(3), "not_moving": fails.count(1), "fail_recover": fails.count(2), "fail_detection": fails.count(0),
                   "waves": stats.get("waves"), "gap_pairs": stats.get("gap_pairs"),
                   "end_position_error_m": round(float(np.linalg.norm(last["estimate_pos"] - c_true)), 3),
