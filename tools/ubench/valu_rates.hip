@@ -76,6 +76,16 @@ KERNELCVT(k_cvt_f32_f64, "v_cvt_f32_f64", double, float)
 KERNELCVT(k_cvt_i32_f64, "v_cvt_i32_f64", double, int)
 KERNELCVT(k_cvt_f64_i32, "v_cvt_f64_i32", int, double)
 KERNEL64(k_lshl_add_u64, I_LSHL_ADD64)
+#define I_CVT_F32_U32(r) "v_cvt_f32_u32 " #r ", " #r
+#define I_SUB_LIT(r) "v_sub_f32 " #r ", 0x4f800000, " #r
+#define I_MUL_LIT(r) "v_mul_f32 " #r ", 0x1f800000, " #r
+#define I_SUB_INL(r) "v_sub_f32 " #r ", 1.0, " #r
+#define I_SUB_SGPR(r) "v_sub_f32 " #r ", s20, " #r
+KERNEL32(k_cvt_f32_u32, I_CVT_F32_U32)
+KERNEL32(k_sub_lit, I_SUB_LIT)
+KERNEL32(k_mul_lit, I_MUL_LIT)
+KERNEL32(k_sub_inl, I_SUB_INL)
+KERNEL32(k_sub_sgpr, I_SUB_SGPR)
 
 int main() {
     float* out;
@@ -89,7 +99,9 @@ int main() {
         {"v_add_lshl_u32", k_add_lshl}, {"v_cvt_pk_u8_f32", k_cvt_pk_u8}, {"v_med3_f32", k_med3}, {"v_add_co_u32", k_add_co},
         {"v_pk_mul_f32", k_pk_mul}, {"v_pk_add_f32", k_pk_add}, {"v_pk_fma_f32", k_pk_fma}, {"v_add_f64", k_add_f64},
         {"v_fma_f64", k_fma_f64}, {"v_fract_f64", k_fract_f64}, {"v_floor_f64", k_floor_f64}, {"v_cvt_f32_f64", k_cvt_f32_f64},
-        {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_lshl_add_u64", k_lshl_add_u64}};
+        {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_lshl_add_u64", k_lshl_add_u64},
+        {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_sub_f32 literal", k_sub_lit}, {"v_mul_f32 literal", k_mul_lit}, {"v_sub_f32 inline", k_sub_inl},
+        {"v_sub_f32 sgpr", k_sub_sgpr}};
     double base = 0;
     for (auto& k : ks) {
         float best = 1e30f;

@@ -152,7 +152,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.img, (size_t)F * H * W + 256));  // tile staging may read up to 111 bytes past a row end
     VO_TRY(dalloc(fs.sum, (size_t)F * (H + 1) * (W + 1) + 64));
     VO_TRY(dalloc(fs.colsum, (size_t)F * nbands * W));
-    VO_TRY(dalloc(fs.quad, (size_t)F * H * W + 64));
+    VO_TRY(dalloc(fs.quad, (size_t)F * ((W + 7) / 8) * 8 * H + 64));  // 8-pixel column strips (vo_detect.hip, quad_index)
     VO_TRY(dalloc(fs.kp_raw, (size_t)F * cap));
     VO_TRY(dalloc(fs.kp, (size_t)F * cap));
     VO_TRY(dalloc(fs.rank, (size_t)F * cap));

@@ -135,7 +135,7 @@ struct FrameSet {
     uint8_t* img = nullptr;      // [F][H][W]
     int32_t* sum = nullptr;      // [F][H+1][W+1]
     int32_t* colsum = nullptr;   // [F][nbands][W]
-    uint32_t* quad = nullptr;    // [F][H*W] bilinear footprints: p(y,x) | p(y,x+1)<<8 | p(y+1,x)<<16 | p(y+1,x+1)<<24
+    uint32_t* quad = nullptr;    // [F][ceil(W/8)][H][8] bilinear footprints p(y,x) | p(y,x+1)<<8 | p(y+1,x)<<16 | p(y+1,x+1)<<24 in 8-pixel column strips
     vo_keypoint* kp_raw = nullptr;  // [F][cap]
     vo_keypoint* kp = nullptr;      // [F][cap] sorted
     int* rank = nullptr;            // [F][cap]

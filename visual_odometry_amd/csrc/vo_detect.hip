@@ -1635,6 +1635,15 @@ __global__ __launch_bounds__(256) void k_orientation(const int32_t* __restrict__
 // (p00 | p01 << 8 | p10 << 16 | p11 << 24), so a sample costs ONE gather instead of two unaligned 16-bit ones
 // (tools/microbench/gather_bench.hip: 2.2-2.5x the gather rate of the u8 image on gfx950).  The last row and
 // column repeat the edge pixel; the sampler only reads footprints with ix < W-1, iy < H-1.
+// Layout of the footprint image: 8-pixel-wide COLUMN STRIPS, strip after strip, rows consecutive inside a strip - the word of
+// pixel (y, x) sits at quad_index(H, y, x).  A 128-byte cache line then holds an 8 x 4 block of pixels instead of 32 x 1, and
+// a gather instruction of the descriptor sampler (8 window rows x 8 columns, rotated: an ~11 x 11 pixel patch) touches ~8
+// lines instead of ~15.  The sampler is bound by exactly that - knock-outs over the four window classes, ms per 128 frames:
+// 19.9 as it was, 15.4 without the loads, 19.2 without the bilinear arithmetic, 17.3 with every load made to hit L1 - and
+// the strips bring it to 18.4 (widths of 4 and 16 pixels: 18.5).
+__host__ __device__ __forceinline__ size_t quad_stride(int H, int W) { return (size_t)((W + 7) >> 3) * 8 * H; }
+__device__ __forceinline__ size_t quad_index(int H, int y, int x) { return (size_t)(x >> 3) * (8 * H) + (size_t)y * 8 + (x & 7); }
+
 __global__ __launch_bounds__(256) void k_quads(const uint8_t* __restrict__ img_base, size_t img_stride, int H, int W,
                                                uint32_t* __restrict__ quad_base) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y, frame = blockIdx.z;
@@ -1643,15 +1652,17 @@ __global__ __launch_bounds__(256) void k_quads(const uint8_t* __restrict__ img_b
     const int x1 = min(x + 1, W - 1), y1 = min(y + 1, H - 1);
     const uint32_t p00 = img[(size_t)y * W + x], p01 = img[(size_t)y * W + x1];
     const uint32_t p10 = img[(size_t)y1 * W + x], p11 = img[(size_t)y1 * W + x1];
-    quad_base[(size_t)frame * img_stride + (size_t)y * W + x] = p00 | (p01 << 8) | (p10 << 16) | (p11 << 24);
+    quad_base[(size_t)frame * quad_stride(H, W) + quad_index(H, y, x)] = p00 | (p01 << 8) | (p10 << 16) | (p11 << 24);
 }
 
 // the same for frames whose rows are 4-byte aligned (W and the frame pitch multiples of four): four pixels per lane from two
-// aligned words + the next byte of each row, one 16-byte store
+// aligned words + the next byte of each row, one 16-byte store.  Eight consecutive lanes fill one 128-byte line of a strip
+// (two lanes per row, four rows), a wavefront eight strips of those four rows.
 __global__ __launch_bounds__(256) void k_quads4(const uint8_t* __restrict__ img_base, size_t img_stride, int H, int W,
                                                 uint32_t* __restrict__ quad_base) {
-    const int x = (blockIdx.x * 256 + threadIdx.x) * 4, y = blockIdx.y, frame = blockIdx.z;
-    if (x >= W) return;
+    const int t = threadIdx.x, frame = blockIdx.z;
+    const int strip = blockIdx.x * 32 + (t >> 3), y = blockIdx.y * 4 + ((t >> 1) & 3), x = strip * 8 + (t & 1) * 4;
+    if (x >= W || y >= H) return;
     const uint8_t* img = img_base + (size_t)frame * img_stride;
     const uint8_t* r0 = img + (size_t)y * W + x;
     const uint8_t* r1 = img + (size_t)min(y + 1, H - 1) * W + x;
@@ -1664,7 +1675,7 @@ __global__ __launch_bounds__(256) void k_quads4(const uint8_t* __restrict__ img_
     q.y = (uint32_t)((a64 >> 8) & 0xffffu) | ((uint32_t)((b64 >> 8) & 0xffffu) << 16);
     q.z = (uint32_t)((a64 >> 16) & 0xffffu) | ((uint32_t)((b64 >> 16) & 0xffffu) << 16);
     q.w = (uint32_t)((a64 >> 24) & 0xffffu) | ((uint32_t)((b64 >> 24) & 0xffffu) << 16);
-    *reinterpret_cast<uint4*>(quad_base + (size_t)frame * img_stride + (size_t)y * W + x) = q;
+    *reinterpret_cast<uint4*>(quad_base + (size_t)frame * quad_stride(H, W) + quad_index(H, y, x)) = q;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1717,7 +1728,7 @@ __device__ __forceinline__ int bilinear_u8(uint32_t q, float a, float b) {
 // column j0, (dxs, dys) the exact step of CB columns.  Coordinates are linear in the column, so the batch lies
 // in the frame interior iff its first and last sample do; then the 2 * U tap loads go out back to back.
 template <int U, int CB, bool CHECK>
-__device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, const uint32_t* __restrict__ quad, int W,
+__device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, const uint32_t* __restrict__ quad, int W, int qs8,
                                              int ncols1, int nrows1, double px0, double py0, double dxs, double dys,
                                              lds_u8* wdst) {
     bool ok = true;
@@ -1737,8 +1748,10 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
             a[u] = (float)__builtin_amdgcn_fract(px);
             b[u] = (float)__builtin_amdgcn_fract(py);
             asm volatile("" : "+v"(a[u]), "+v"(b[u]));  // keep the fractions as floats (not as doubles) across the loads
-            // 32-bit byte offset from the frame's base (a frame's footprint image is < 4 GB): scalar base + vector offset
-            const uint32_t boff = ((uint32_t)__mul24((int)py, W) + (uint32_t)(int)px) << 2;
+            // 32-bit byte offset from the frame's base (a frame's footprint image is < 4 GB): scalar base + vector offset.
+            // The footprint image is stored in 8-pixel-wide column strips (quad_index): x >> 3 picks the strip, (y, x & 7) the word
+            const uint32_t xi = (uint32_t)(int)px, yi = (uint32_t)(int)py;
+            const uint32_t boff = ((uint32_t)__mul24((int)(xi >> 3), qs8) + ((yi << 3) | (xi & 7u))) << 2;
             q[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(quad) + boff);
             px += dxs;
             py += dys;
@@ -1798,7 +1811,7 @@ int vo_build_window_tables(vo_ctx* ctx) {
 // flight per lane; a strip is G groups of RB rows per wavefront (sampled back to back, then one row pass and one fold);
 // CH work-queue tickets per atomic.
 template <int WHI, int NW, int RB, int UMAX, int G, int CH>
-__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
+__global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 320 ? 4 : 5, 8))) void k_describe_tiled(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                             const uint32_t* __restrict__ quad_base,
                                                             const int32_t* __restrict__ sum_base, size_t sum_stride, int H,
                                                             int W, vo_keypoint* __restrict__ kp_base,
@@ -1816,15 +1829,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
     static_assert(((kPitch / 4) & 1) == 1, "strip pitch must be an odd number of dwords");
     __shared__ CellTab s_cell[kPatch + 1];
     // strip-phase arrays; the gradient planes of the last phase (s_grad, 3200 B) reuse the same bytes
-    // the per-pixel decimation table: an LDS copy for the 128-320 px class only.  The largest class is bound by LDS per
-    // workgroup (46 KB with the copy = three workgroups per CU, 38 KB without = four: 6.95 -> 6.31 ms); the one-wavefront classes (small windows)
-    // read the context's global table instead - their occupancy is bounded by LDS per workgroup (measured both ways)
-    constexpr bool kPixLds = NW > 1 && WHI <= kMidWin;  // the largest class trades the copy for a fourth workgroup per CU
-    constexpr int kOffPix = 0, kOffSx = kOffPix + (kPixLds ? WHI * (int)sizeof(PixTab) : 0), kOffSy = kOffSx + WHI * 4;
+    constexpr int kOffSx = 0, kOffSy = kOffSx + WHI * 4;
     constexpr int kOffWin = (kOffSy + WHI * 4 + 15) & ~15, kOffRowv = (kOffWin + RS * kPitch + 15) & ~15;
     constexpr int kStripBytes = kOffRowv + NBUF * RS * (kPatch + 1) * 4, kGradBytes = 2 * kPatch * kPatch * 4;
     __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStripBytes > kGradBytes ? kStripBytes : kGradBytes];
-    PixTab* s_pix = reinterpret_cast<PixTab*>(s_raw + kOffPix);
     float* s_sx = reinterpret_cast<float*>(s_raw + kOffSx);   // start of every window row (sequential float accumulation)
     float* s_sy = reinterpret_cast<float*>(s_raw + kOffSy);
     uint8_t* s_win = s_raw + kOffWin;
@@ -1898,20 +1906,15 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
         const float s = size * 1.2f / 9.0f;
         const int win = (int)((kPatch + 1) * s);
         const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
-        const uint32_t* __restrict__ quad = quad_base + (size_t)frame * img_stride;
+        const uint32_t* __restrict__ quad = quad_base + (size_t)frame * quad_stride(H, W);
         const double scale = (double)win / (kPatch + 1);
         const int iscale = d_cvRoundD(scale);
         const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
         // the window size's decimation tables (k_build_win_tables)
-        const PixTab* __restrict__ pix_win = kPixLds ? s_pix : g_pix + (size_t)win * kWinTabPitch;
-        if (!area_fast) {
-            if (tid <= kPatch) s_cell[tid] = g_cell[(size_t)win * (kPatch + 1) + tid];
-            if (kPixLds)
-                for (int j = tid; j < win; j += NT) s_pix[j] = g_pix[(size_t)win * kWinTabPitch + j];
-        }
+        if (!area_fast && tid <= kPatch) s_cell[tid] = g_cell[(size_t)win * (kPatch + 1) + tid];
         if (tid == 0) n_code = *(volatile const int*)&list[min(n_item, n_items - 1)];  // look-ahead stage 2: list entry
         const float win_offset = -(float)(win - 1) / 2;
-        const int ncols1 = W - 1, nrows1 = H - 1;
+        const int ncols1 = W - 1, nrows1 = H - 1, qs8 = 8 * H;
         const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
         const double dxs = (double)CB * dcos, dys = (double)CB * ndsin;  // exact: CB is a power of two
         bool bad = force_seq != 0 || !(exact_step(cos_dir) && exact_step(sin_dir));
@@ -1948,9 +1951,16 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
             rp_w1 = n >= 1 ? rp_am : 0.f, rp_w2 = n >= 2 ? rp_am : 0.f, rp_w3 = n >= 3 ? rp_am : 0.f;
         }
         const int rp_nmin = __builtin_amdgcn_readfirstlane(myct.pad) & 0xffff, rp_nmax = __builtin_amdgcn_readfirstlane(myct.pad) >> 16;
-        // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane)
-        float vacc = 0.f;
+        // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane; integer scales)
         int viacc = 0, dy = 0, left = iscale;
+        // Vertical pass of the general case: lane (g, column) of the first wavefront, g = 0..2, folds destination rows g, g + 3,
+        // g + 6, ... - three destination rows are in flight at once, each added up over ITS source rows in row order, so a
+        // strip of RS rows takes about RS / 3 dependent steps instead of RS.  A destination row that straddles two strips keeps
+        // its partial sum in the lane (f_carry).  Row weights come from the cell table (the y table is the x table).
+        // Only the destination row and its partial sum live across the strips (as vacc / dy did): the row's table entry is
+        // re-read from LDS in every strip, the sampling loop has no registers to spare.
+        int f_d = tid / (kPatch + 1);  // destination row this lane folds next (> kPatch: done)
+        float f_carry = 0.f;           // its partial sum when it began in an earlier strip
 
         for (int i0 = 0, sidx = 0; i0 < win; i0 += RS, sidx ^= (NBUF - 1)) {
             const int wrow0 = i0 + wave * WR;  // first row of this wavefront's part of the strip
@@ -1979,7 +1989,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
 #define VO_BATCH(UU)                                                                                                          \
     {                                                                                                                         \
         const double jd = (double)(jb + c);                                                                                   \
-        sample_batch<UU, CB, CK>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
+        sample_batch<UU, CB, CK>(img, quad, W, qs8, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
                                  dys, wrow + jb + c);                                                                         \
         jb += UU * CB;                                                                                                        \
     }
@@ -1995,10 +2005,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                     if (jb < win) {  // last, partial group of columns: lanes past the window repeat its last column
                         const int jc = min(jb + c, win - 1);
                         const double jd = (double)jc;
-                        sample_batch<1, CB, CK>(img, quad, W, ncols1, nrows1, __builtin_fma(jd, dcos, sxd),
+                        sample_batch<1, CB, CK>(img, quad, W, qs8, ncols1, nrows1, __builtin_fma(jd, dcos, sxd),
                                                 __builtin_fma(jd, ndsin, syd), dxs, dys, wrow + jc);
                     }
                 };
+                // interior AND every coordinate a multiple of 2^-32: the fixed-point walk; anything else (a window across the frame
+                // border; |cos|, |sin| or a row start below 2^-9, 0.3 % of the keypoints) takes the double-precision walk with its
+                // per-batch interior test
                 if (__ballot(!row_in) == 0ull)
                     sample_rows(std::false_type{});
                 else
@@ -2066,10 +2079,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                 __syncthreads();  // strip complete (the other buffer half is free: its fold ended before this barrier)
             else
                 wave_sync_lds();
-            if (tid <= kPatch) {
-                const int nrows = min(RS, win - i0);
-                const int ob = sidx * RS * (kPatch + 1) + tid;
-                if (area_fast) {
+            if (area_fast) {
+                if (tid <= kPatch) {
+                    const int nrows = min(RS, win - i0);
+                    const int ob = sidx * RS * (kPatch + 1) + tid;
                     for (int q = 0; q < nrows; q++) {
                         viacc += s_rowi[ob + q * (kPatch + 1)];
                         if (--left == 0) {
@@ -2086,30 +2099,59 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(5, 8)))
                             left = iscale;
                         }
                     }
-                } else {
-                    // eight rows at a time: their table entries and row sums are read together, the adds stay in row order
-                    const lds_f32* vrow = (const lds_f32*)s_rowv + ob;
-                    const int ilast = (nrows - 1) * (kPatch + 1);
-                    for (int q0 = 0, i8 = 0; q0 < nrows; q0 += 8, i8 += 8 * (kPatch + 1)) {
-                        PixTab t[8];
-                        float val[8];
+                }
+            } else if (tid < 3 * (kPatch + 1)) {
+                const int f_dx = tid - (tid / (kPatch + 1)) * (kPatch + 1);
+                int f_first = 0, f_last = -1, f_sx2 = 0, f_tail = 0;
+                float f_wfirst = 0.f, f_amid = 0.f, f_atail = 0.f;
+                auto fold_load = [&]() {  // source rows and weights of destination row f_d
+                    if (f_d <= kPatch) {
+                        const CellTab ct = s_cell[f_d];
+                        f_first = ct.has_head ? ct.sx1 - 1 : ct.sx1;
+                        f_last = ct.has_tail ? ct.sx2 : ct.sx2 - 1;
+                        f_sx2 = ct.sx2;
+                        f_tail = ct.has_tail;
+                        f_wfirst = ct.has_head ? ct.a_head : (ct.sx1 < ct.sx2 ? ct.a_mid : ct.a_tail);
+                        f_amid = ct.a_mid;
+                        f_atail = ct.a_tail;
+                    } else {
+                        f_first = 1 << 30;  // never starts
+                    }
+                };
+                fold_load();
+                const int r_end = min(i0 + RS, win);  // source rows [i0, r_end) are in this strip's buffer
+                const lds_f32* vcol = (const lds_f32*)s_rowv + (sidx * RS * (kPatch + 1) + f_dx) - i0 * (kPatch + 1);  // row q at vcol[q * 21]
+                while (f_first < r_end) {
+                    int q = max(f_first, i0);
+                    float acc = f_carry;
+                    if (q == f_first) {  // the row begins here: OpenCV assigns beta * buf to the open sum
+                        acc = f_wfirst * vcol[q * (kPatch + 1)];
+                        q++;
+                    }
+                    const int qm = min(f_sx2, r_end);  // full-weight rows [q, qm), four reads in flight, adds in row order
+                    for (; q < qm; q += 4) {
+                        float v[4];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            const int q = min(q0 + u, nrows - 1);
-                            t[u] = pix_win[i0 + q];
-                            val[u] = vrow[min(i8 + u * (kPatch + 1), ilast)];
-                        }
+                        for (int u = 0; u < 4; u++) v[u] = vcol[min(q + u, qm - 1) * (kPatch + 1)];
 #pragma unroll
-                        for (int u = 0; u < 8; u++) {
-                            if (q0 + u < nrows) {
-                                vacc += t[u].w_cur * val[u];
-                                if (__builtin_amdgcn_readfirstlane(t[u].end)) {  // same row in every lane
-                                    s_patch[dy * (kPatch + 1) + tid] = (uint8_t)saturate_u8(d_cvRoundF(vacc));
-                                    dy++;
-                                    vacc = t[u].w_next * val[u];
-                                }
-                            }
+                        for (int u = 0; u < 4; u++) {
+                            const float a = acc + f_amid * v[u];
+                            acc = q + u < qm ? a : acc;
                         }
+                    }
+                    q = max(min(q, qm), min(f_first + 1, r_end));  // the row after the last one added
+                    if (f_tail && q == f_sx2 && q < r_end) {
+                        acc += f_atail * vcol[q * (kPatch + 1)];
+                        q++;
+                    }
+                    if (q > f_last) {  // destination row complete
+                        s_patch[f_d * (kPatch + 1) + f_dx] = (uint8_t)saturate_u8(d_cvRoundF(acc));
+                        f_d += 3;
+                        f_carry = 0.f;
+                        fold_load();
+                    } else {  // continues in the next strip
+                        f_carry = acc;
+                        break;
                     }
                 }
             }
@@ -2283,7 +2325,7 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
     const bool quads_beside = describe && !ctx->profiling;
     auto launch_quads = [&](hipStream_t st) {
         if (fs.W % 4 == 0 && fs.img_stride() % 4 == 0)
-            hipLaunchKernelGGL(k_quads4, dim3((fs.W / 4 + 255) / 256, fs.H, fs.F), dim3(256), 0, st, fs.img, fs.img_stride(), fs.H, fs.W,
+            hipLaunchKernelGGL(k_quads4, dim3(((fs.W + 7) / 8 + 31) / 32, (fs.H + 3) / 4, fs.F), dim3(256), 0, st, fs.img, fs.img_stride(), fs.H, fs.W,
                                fs.quad);
         else
             hipLaunchKernelGGL(k_quads, dim3((fs.W + 255) / 256, fs.H, fs.F), dim3(256), 0, st, fs.img, fs.img_stride(), fs.H, fs.W, fs.quad);
