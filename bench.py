@@ -32,7 +32,7 @@ N_SIMD, VALU_CLOCK_HZ = 1024, 2.4e9
 SAMPLE_ISSUE_CYCLES = 86  # VALU issue cycles of one bilinear window sample per wavefront
 MFMA_EXEC_FACTOR = 25.0 / 8.0  # executed bf16 MFMA flop per algorithmic FP32 flop of the matcher (split-bf16 products + norm step)
 C3_STEP_M, C3_DEPTH_M, C3_RELIEF_M = 0.5, 6.0, 1.8  # the configs[2] stand-in scene (synth.sequence_c3)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_hbm_traffic.json")  # PMC passes of `bench.py --profile-region`
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_hbm_traffic.json")  # PMC passes of `bench.py --profile-region`
 
 
 def layer_samples(h, w):
@@ -42,7 +42,7 @@ def layer_samples(h, w):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=40)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="frame pairs per step per GPU (~75 MB of HBM per pair)")
     ap.add_argument("--scenes", type=int, default=64, help="distinct synthetic pairs per GPU (cycled to fill the batch)")
@@ -340,6 +340,11 @@ def main():
                 cyc = dur_s * VALU_CLOCK_HZ * N_SIMD / max(wsamples, 1.0)
                 out["valu_issue"] = {"window_samples_per_launch": round(cls_samples[name]), "cycles_per_wavefront_sample": round(cyc, 1),
                                      "floor_cycles": SAMPLE_ISSUE_CYCLES, "frac_of_floor": round(SAMPLE_ISSUE_CYCLES / cyc, 4)}
+                # ... and by the gathers themselves (round 3 knock-outs, DESIGN.md 5.1: the kernels lose 0.6 ms of 19.9 without the
+                # bilinear arithmetic and 4.4 ms without the loads): one 64-lane gather of 4-byte footprint words per wavefront-sample,
+                # each touching ~8 cache lines of the strip-tiled footprint image (L2 -> L1 fills at 64 B per clock and CU)
+                out["gathers"] = {"wavefront_gathers_per_launch": round(wsamples), "ns_per_gather_per_cu": round(dur_s * 1e9 * 256 / max(wsamples, 1.0), 2),
+                                  "clocks_per_gather_per_cu": round(dur_s * VALU_CLOCK_HZ * 256 / max(wsamples, 1.0), 1)}
             if bound == "mfma" and args.matcher != "fp32":
                 out["note"] = ("executed bf16 MFMA flop (3.125 x the algorithmic 2*64*N1*N2) against the dense bf16 peak; "
                                f"algorithmic rate {round(work / dur_s / 1e12, 1)} TFLOP/s = "
