@@ -1751,7 +1751,10 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
             // 32-bit byte offset from the frame's base (a frame's footprint image is < 4 GB): scalar base + vector offset.
             // The footprint image is stored in 8-pixel-wide column strips (quad_index): x >> 3 picks the strip, (y, x & 7) the word
             const uint32_t xi = (uint32_t)(int)px, yi = (uint32_t)(int)py;
-            const uint32_t boff = ((uint32_t)__mul24((int)(xi >> 3), qs8) + ((yi << 3) | (xi & 7u))) << 2;
+            // byte offset 4 * ((x >> 3) * 8H + 8y + (x & 7)) = (x >> 3) * (32H - 32) + 32y + 4x: four instructions
+            uint32_t boff = (uint32_t)__mul24((int)(xi >> 3), qs8);
+            asm("v_lshl_add_u32 %0, %1, 5, %0" : "+v"(boff) : "v"(yi));  // (the compiler's choice is two shifts and a three-way add)
+            asm("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(boff) : "v"(xi));
             q[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(quad) + boff);
             px += dxs;
             py += dys;
@@ -1914,7 +1917,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
         if (!area_fast && tid <= kPatch) s_cell[tid] = g_cell[(size_t)win * (kPatch + 1) + tid];
         if (tid == 0) n_code = *(volatile const int*)&list[min(n_item, n_items - 1)];  // look-ahead stage 2: list entry
         const float win_offset = -(float)(win - 1) / 2;
-        const int ncols1 = W - 1, nrows1 = H - 1, qs8 = 8 * H;
+        const int ncols1 = W - 1, nrows1 = H - 1, qs8 = 32 * H - 32;  // see sample_batch
         const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
         const double dxs = (double)CB * dcos, dys = (double)CB * ndsin;  // exact: CB is a power of two
         bool bad = force_seq != 0 || !(exact_step(cos_dir) && exact_step(sin_dir));
