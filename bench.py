@@ -254,16 +254,20 @@ def main():
         stats = {}
         # warm-up: the same replay once (the context keeps its sequence / pair batches, so the timed run allocates nothing)
         replay.replay_sharded(ctx3, c3.frames, stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev)
-        barrier()
-        t3 = time.perf_counter()
-        recs = replay.replay_sharded(ctx3, c3.frames, stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev, stats=stats)
-        barrier()
-        d3 = max_over_ranks(time.perf_counter() - t3)
+        d3s = []
+        for _ in range(3):  # three timed replays, the fastest is reported (all three are in the line: `seconds_all`)
+            barrier()
+            t3 = time.perf_counter()
+            stats = {}
+            recs = replay.replay_sharded(ctx3, c3.frames, stamps, alt, c3.K, np.eye(3), np.zeros(3), rank, world, device=coll_dev, stats=stats)
+            barrier()
+            d3s.append(max_over_ranks(time.perf_counter() - t3))
+        d3 = min(d3s)
         fails = [r["fail"] for r in recs]
         last = [r for r in recs if "estimate_pos" in r][-1]  # the last iteration that produced a pose (a stationary tail publishes none)
         c_true = -c3.Rw[last["frame"]].T @ c3.tw[last["frame"]]
         c3_out = {"value": round((n3 - 1) / d3, 2), "unit": "frames/s (one loop iteration of the node per frame)", "frames": n3, "size": "640x505",
-                  "K": "config/rapallo_intrinsic.yaml via updateCameraMatrix", "ranks": world,
+                  "K": "config/rapallo_intrinsic.yaml via updateCameraMatrix", "ranks": world, "seconds_all": [round(v, 4) for v in d3s],
                   "scene": {"step_m": C3_STEP_M, "depth_m": C3_DEPTH_M, "relief_m": C3_RELIEF_M, "stationary_frames": 25}, "seconds": round(d3, 4),
                   "success": fails.count(3), "not_moving": fails.count(1), "fail_recover": fails.count(2), "fail_detection": fails.count(0),
                   "waves": stats.get("waves"), "gap_pairs": stats.get("gap_pairs"),

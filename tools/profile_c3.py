@@ -8,11 +8,11 @@ from visual_odometry_amd._abi import default_params
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 512
-    c3 = synth.sequence_c3(n, seed=3003, workers=8)
+    c3 = synth.sequence_c3(n, seed=3003, step_m=0.5, depth=6.0, relief=1.8, workers=8)
     prm = default_params()
     ctx = Context(prm)
     stamps = np.arange(n) * 0.1
-    alt = np.full(n, 7.0)
+    alt = np.full(n, 6.0)
     for chunk in (64, 128, 256):
         replay.replay_sharded(ctx, c3.frames[: 2 * chunk], stamps[: 2 * chunk], alt[: 2 * chunk], c3.K, np.eye(3), np.zeros(3), 0, 1, chunk=chunk)
         ts = []
