@@ -1,8 +1,8 @@
 #!/bin/bash
-# A/B of two builds of the library (exp_lib4.so, exp_lib5.so): stage times of the headline workload (each kernel alone)
+# A/B of experimental builds of the library (exp_lib$e.so for e in $LIBS, default "4 5"): stage times of the headline workload (each kernel alone)
 cd "$GRAFT_REPO_ROOT" || exit 1
 cp visual_odometry_amd/libvo_mi355x.so /tmp/good.so
-for e in 4 5; do
+for e in ${LIBS:-4 5}; do
   cp exp_lib$e.so visual_odometry_amd/libvo_mi355x.so
   echo "== LIB $e"
   timeout -k 10 200 python3 bench.py --profile-region --steps 4 2>/dev/null | python3 -c "

@@ -87,6 +87,181 @@ KERNEL32(k_mul_lit, I_MUL_LIT)
 KERNEL32(k_sub_inl, I_SUB_INL)
 KERNEL32(k_sub_sgpr, I_SUB_SGPR)
 
+#define I_X0(r) "v_and_b32 " #r ", 0xff, " #r
+KERNEL32(k_x0, I_X0)
+#define I_X1(r) "v_or_b32 " #r ", 3, " #r
+KERNEL32(k_x1, I_X1)
+#define I_X2(r) "v_xor_b32 " #r ", 5, " #r
+KERNEL32(k_x2, I_X2)
+#define I_X3(r) "v_lshlrev_b32 " #r ", 1, " #r
+KERNEL32(k_x3, I_X3)
+#define I_X4(r) "v_lshrrev_b32 " #r ", 1, " #r
+KERNEL32(k_x4, I_X4)
+#define I_X5(r) "v_ashrrev_i32 " #r ", 1, " #r
+KERNEL32(k_x5, I_X5)
+#define I_X6(r) "v_max_f32 " #r ", 1.0, " #r
+KERNEL32(k_x6, I_X6)
+#define I_X7(r) "v_min_u32 " #r ", 7, " #r
+KERNEL32(k_x7, I_X7)
+#define I_X8(r) "v_mov_b32 " #r ", " #r
+KERNEL32(k_x8, I_X8)
+#define I_X9(r) "v_cndmask_b32 " #r ", 1.0, " #r ", vcc"
+KERNEL32(k_x9, I_X9)
+#define I_X10(r) "v_fmac_f32 " #r ", 0.5, " #r
+KERNEL32(k_x10, I_X10)
+#define I_X11(r) "v_fma_f32 " #r ", " #r ", 0.5, 1.0"
+KERNEL32(k_x11, I_X11)
+#define I_X12(r) "v_mul_u32_u24 " #r ", 3, " #r
+KERNEL32(k_x12, I_X12)
+#define I_X13(r) "v_mad_u32_u24 " #r ", " #r ", 3, 1"
+KERNEL32(k_x13, I_X13)
+#define I_X14(r) "v_add3_u32 " #r ", " #r ", 3, 1"
+KERNEL32(k_x14, I_X14)
+#define I_X15(r) "v_lshl_add_u32 " #r ", " #r ", 2, 1"
+KERNEL32(k_x15, I_X15)
+#define I_X16(r) "v_lshl_or_b32 " #r ", " #r ", 2, 1"
+KERNEL32(k_x16, I_X16)
+#define I_X17(r) "v_and_or_b32 " #r ", " #r ", 63, 1"
+KERNEL32(k_x17, I_X17)
+#define I_X18(r) "v_bfe_u32 " #r ", " #r ", 8, 8"
+KERNEL32(k_x18, I_X18)
+#define I_X19(r) "v_bfi_b32 " #r ", 63, " #r ", 1"
+KERNEL32(k_x19, I_X19)
+#define I_X20(r) "v_alignbyte_b32 " #r ", " #r ", " #r ", 1"
+KERNEL32(k_x20, I_X20)
+#define I_X21(r) "v_perm_b32 " #r ", " #r ", " #r ", 1"
+KERNEL32(k_x21, I_X21)
+#define I_X22(r) "v_sad_u32 " #r ", " #r ", 3, 1"
+KERNEL32(k_x22, I_X22)
+#define I_X23(r) "v_cmp_lt_f32 vcc, 1.0, " #r "\n v_cndmask_b32 " #r ", 2.0, " #r ", vcc"
+KERNEL32(k_x23, I_X23)
+#define I_X24(r) "v_floor_f32 " #r ", " #r
+KERNEL32(k_x24, I_X24)
+#define I_X25(r) "v_fract_f32 " #r ", " #r
+KERNEL32(k_x25, I_X25)
+#define I_X26(r) "v_cvt_f32_i32 " #r ", " #r
+KERNEL32(k_x26, I_X26)
+#define I_X27(r) "v_cvt_i32_f32 " #r ", " #r
+KERNEL32(k_x27, I_X27)
+#define I_X28(r) "v_rndne_f32 " #r ", " #r
+KERNEL32(k_x28, I_X28)
+#define I_X29(r) "v_add_f32_dpp " #r ", " #r ", " #r " row_shr:1 row_mask:0xf bank_mask:0xf"
+KERNEL32(k_x29, I_X29)
+#define I_X30(r) "v_mov_b32_dpp " #r ", " #r " row_shr:1 row_mask:0xf bank_mask:0xf"
+KERNEL32(k_x30, I_X30)
+#define I_X31(r) "v_sub_f32_e64 " #r ", -" #r ", 1.0"
+KERNEL32(k_x31, I_X31)
+#define I_X32(r) "v_mul_f32_e64 " #r ", " #r ", 0.5"
+KERNEL32(k_x32, I_X32)
+#define I_X33(r) "v_ldexp_f32 " #r ", " #r ", 1"
+KERNEL32(k_x33, I_X33)
+#define I_X34(r) "v_add_u32 " #r ", s20, " #r
+KERNEL32(k_x34, I_X34)
+#define I_X35(r) "v_sub_u32_e64 " #r ", " #r ", 3"
+KERNEL32(k_x35, I_X35)
+// SDWA byte select on a float multiply: the byte read as a float is the denormal b * 2^-149; with the other factor scaled by
+// 2^127 the product is fl(b * w) * 2^-22 (same rounding: scaling by a power of two, result normal).  Rate and exactness.
+__global__ __launch_bounds__(256) void k_mul_sdwa(float* out) {
+    uint32_t q0 = threadIdx.x * 2654435761u, q1 = q0 ^ 0x5bd1e995u, q2 = q0 + 77u, q3 = q1 + 1234567u;
+    float w0 = (threadIdx.x + 0.3f) * 0x1p100f, w1 = w0 * 1.5f, w2 = w0 * 0.7f, w3 = w0 * 0.2f;
+    float d0, d1, d2, d3, d4, d5, d6, d7;
+    for (int i = 0; i < kIters; i++) {
+        asm volatile("v_mul_f32_sdwa %0, %8, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD\n"
+                     "v_mul_f32_sdwa %1, %9, %13 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+                     "v_mul_f32_sdwa %2, %10, %14 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+                     "v_mul_f32_sdwa %3, %11, %15 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n"
+                     "v_mul_f32_sdwa %4, %8, %13 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD\n"
+                     "v_mul_f32_sdwa %5, %9, %14 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD\n"
+                     "v_mul_f32_sdwa %6, %10, %15 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD\n"
+                     "v_mul_f32_sdwa %7, %11, %12 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                     : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7;
+}
+__global__ __launch_bounds__(256) void k_mul_vv(float* out) {  // plain v_mul_f32 with two VGPR sources, no dependency chain
+    float q0 = threadIdx.x * 1.1f, q1 = q0 + 3, q2 = q0 + 77, q3 = q1 + 12;
+    float w0 = (threadIdx.x + 0.3f), w1 = w0 * 1.5f, w2 = w0 * 0.7f, w3 = w0 * 0.2f;
+    float d0, d1, d2, d3, d4, d5, d6, d7;
+    for (int i = 0; i < kIters; i++) {
+        asm volatile("v_mul_f32 %0, %8, %12\nv_mul_f32 %1, %9, %13\nv_mul_f32 %2, %10, %14\nv_mul_f32 %3, %11, %15\n"
+                     "v_mul_f32 %4, %8, %13\nv_mul_f32 %5, %9, %14\nv_mul_f32 %6, %10, %15\nv_mul_f32 %7, %11, %12"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                     : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7;
+}
+__global__ __launch_bounds__(256) void k_mul_denorm(float* out) {  // plain v_mul_f32 whose first source is a denormal (no SDWA)
+    float q0 = __uint_as_float(threadIdx.x & 255u), q1 = __uint_as_float((threadIdx.x * 7u) & 255u), q2 = __uint_as_float(200u), q3 = __uint_as_float(3u);
+    float w0 = (threadIdx.x + 0.3f) * 0x1p100f, w1 = w0 * 1.5f, w2 = w0 * 0.7f, w3 = w0 * 0.2f;
+    float d0, d1, d2, d3, d4, d5, d6, d7;
+    for (int i = 0; i < kIters; i++) {
+        asm volatile("v_mul_f32 %0, %8, %12\nv_mul_f32 %1, %9, %13\nv_mul_f32 %2, %10, %14\nv_mul_f32 %3, %11, %15\n"
+                     "v_mul_f32 %4, %8, %13\nv_mul_f32 %5, %9, %14\nv_mul_f32 %6, %10, %15\nv_mul_f32 %7, %11, %12"
+                     : "=&v"(d0), "=&v"(d1), "=&v"(d2), "=&v"(d3), "=&v"(d4), "=&v"(d5), "=&v"(d6), "=&v"(d7)
+                     : "v"(q0), "v"(q1), "v"(q2), "v"(q3), "v"(w0), "v"(w1), "v"(w2), "v"(w3));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = d0 + d1 + d2 + d3 + d4 + d5 + d6 + d7;
+}
+// does the FP32 rate survive in a mixed stream?  four v_add_f32 and four v_add_u32 per iteration, interleaved or grouped
+__global__ __launch_bounds__(256) void k_mix_interleaved(float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3;
+    unsigned i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
+    for (int i = 0; i < kIters; i++) {
+        asm volatile("v_add_f32 %0, 1.0, %0\nv_add_u32 %4, 3, %4\nv_add_f32 %1, 1.0, %1\nv_add_u32 %5, 3, %5\n"
+                     "v_add_f32 %2, 1.0, %2\nv_add_u32 %6, 3, %6\nv_add_f32 %3, 1.0, %3\nv_add_u32 %7, 3, %7"
+                     : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + (float)(i0 + i1 + i2 + i3);
+}
+__global__ __launch_bounds__(256) void k_mix_grouped(float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1, r2 = r0 + 2, r3 = r0 + 3;
+    unsigned i0 = threadIdx.x, i1 = i0 + 1, i2 = i0 + 2, i3 = i0 + 3;
+    for (int i = 0; i < kIters; i++) {
+        asm volatile("v_add_f32 %0, 1.0, %0\nv_add_f32 %1, 1.0, %1\nv_add_f32 %2, 1.0, %2\nv_add_f32 %3, 1.0, %3\n"
+                     "v_add_u32 %4, 3, %4\nv_add_u32 %5, 3, %5\nv_add_u32 %6, 3, %6\nv_add_u32 %7, 3, %7"
+                     : "+v"(r0), "+v"(r1), "+v"(r2), "+v"(r3), "+v"(i0), "+v"(i1), "+v"(i2), "+v"(i3));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1 + r2 + r3 + (float)(i0 + i1 + i2 + i3);
+}
+// a dependent chain of v_sub_f32 (each reads the previous result), as in a box sum
+__global__ __launch_bounds__(256) void k_sub_chain(float* out) {
+    float r0 = threadIdx.x, r1 = r0 + 1;
+    for (int i = 0; i < kIters; i++) {
+        asm volatile("v_sub_f32 %0, %0, %1\nv_sub_f32 %1, %1, %0\nv_sub_f32 %0, %0, %1\nv_sub_f32 %1, %1, %0\n"
+                     "v_sub_f32 %0, %0, %1\nv_sub_f32 %1, %1, %0\nv_sub_f32 %0, %0, %1\nv_sub_f32 %1, %1, %0"
+                     : "+v"(r0), "+v"(r1));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = r0 + r1;
+}
+__global__ __launch_bounds__(256) void k_subu_chain(float* out) {
+    unsigned r0 = threadIdx.x, r1 = r0 + 1;
+    for (int i = 0; i < kIters; i++) {
+        asm volatile("v_sub_u32 %0, %0, %1\nv_sub_u32 %1, %1, %0\nv_sub_u32 %0, %0, %1\nv_sub_u32 %1, %1, %0\n"
+                     "v_sub_u32 %0, %0, %1\nv_sub_u32 %1, %1, %0\nv_sub_u32 %0, %0, %1\nv_sub_u32 %1, %1, %0"
+                     : "+v"(r0), "+v"(r1));
+    }
+    out[blockIdx.x * 256 + threadIdx.x] = (float)(r0 + r1);
+}
+// exactness: fl(b * w) against the SDWA/denormal product times 2^22, for every byte value and 2^16 weights in [0, 1]
+__global__ __launch_bounds__(256) void k_sdwa_check(unsigned* bad, float* worst) {
+    const unsigned t = blockIdx.x * 256 + threadIdx.x;  // weight index
+    unsigned h = t * 2654435761u;
+    h ^= h >> 15;
+    float w = (float)(h >> 8) * 0x1p-24f;        // 24-bit fraction in [0, 1)
+    if ((t & 7u) == 0) w = (float)(h >> 20) * 0x1p-40f;  // small weights too (multiples of 2^-40)
+    if (t == 1) w = 1.f;
+    if (t == 2) w = 0.f;
+    const float ws = w * 0x1p127f;
+    for (unsigned b = 0; b < 256; b++) {
+        const unsigned q = b << 8;
+        float d;
+        asm volatile("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(d) : "v"(q), "v"(ws));
+        const float ref = (float)b * w;
+        if (d * 0x1p22f != ref) atomicAdd(bad, 1u);
+    }
+}
+
 int main() {
     float* out;
     const int blocks = 256 * 8;  // 8 workgroups of 4 wavefronts per CU: 8 wavefronts per SIMD
@@ -101,7 +276,10 @@ int main() {
         {"v_fma_f64", k_fma_f64}, {"v_fract_f64", k_fract_f64}, {"v_floor_f64", k_floor_f64}, {"v_cvt_f32_f64", k_cvt_f32_f64},
         {"v_cvt_i32_f64", k_cvt_i32_f64}, {"v_cvt_f64_i32", k_cvt_f64_i32}, {"v_lshl_add_u64", k_lshl_add_u64},
         {"v_cvt_f32_u32", k_cvt_f32_u32}, {"v_sub_f32 literal", k_sub_lit}, {"v_mul_f32 literal", k_mul_lit}, {"v_sub_f32 inline", k_sub_inl},
-        {"v_sub_f32 sgpr", k_sub_sgpr}};
+        {"v_sub_f32 sgpr", k_sub_sgpr}, {"v_mul_f32 vgpr,vgpr", k_mul_vv}, {"v_mul_f32 denormal", k_mul_denorm},
+        {"v_mul_f32_sdwa byte", k_mul_sdwa}, {"4 add_f32 + 4 add_u32 interleaved", k_mix_interleaved},
+        {"4 add_f32 + 4 add_u32 grouped", k_mix_grouped}, {"v_sub_f32 dependent chain", k_sub_chain}, {"v_sub_u32 dependent chain", k_subu_chain},
+        {"v_and_b32", k_x0}, {"v_or_b32", k_x1}, {"v_xor_b32", k_x2}, {"v_lshlrev_b32", k_x3}, {"v_lshrrev_b32", k_x4}, {"v_ashrrev_i32", k_x5}, {"v_max_f32", k_x6}, {"v_min_u32", k_x7}, {"v_mov_b32", k_x8}, {"v_cndmask_b32", k_x9}, {"v_fmac_f32", k_x10}, {"v_fma_f32", k_x11}, {"v_mul_u32_u24", k_x12}, {"v_mad_u32_u24", k_x13}, {"v_add3_u32", k_x14}, {"v_lshl_add_u32", k_x15}, {"v_lshl_or_b32", k_x16}, {"v_and_or_b32", k_x17}, {"v_bfe_u32", k_x18}, {"v_bfi_b32", k_x19}, {"v_alignbyte_b32", k_x20}, {"v_perm_b32", k_x21}, {"v_sad_u32", k_x22}, {"v_cmp_lt_f32+cndmask", k_x23}, {"v_floor_f32", k_x24}, {"v_fract_f32", k_x25}, {"v_cvt_f32_i32", k_x26}, {"v_cvt_i32_f32", k_x27}, {"v_rndne_f32", k_x28}, {"v_add_f32 dpp row_shr", k_x29}, {"v_mov_b32 dpp", k_x30}, {"v_sub_f32 neg mod (e64)", k_x31}, {"v_mul_f32 e64", k_x32}, {"v_ldexp_f32", k_x33}, {"v_add_u32 sgpr", k_x34}, {"v_sub_u32 e64", k_x35}};
     double base = 0;
     for (auto& k : ks) {
         float best = 1e30f;
@@ -119,5 +297,12 @@ int main() {
         if (base == 0) base = per_instr_ns;
         printf("%-18s %7.3f ms  %6.3f ns per wavefront instruction per SIMD  = %5.2f x v_add_f32\n", k.name, best, per_instr_ns, per_instr_ns / base);
     }
+    unsigned* bad;
+    CHK(hipMalloc(&bad, 4));
+    CHK(hipMemset(bad, 0, 4));
+    hipLaunchKernelGGL(k_sdwa_check, dim3(256), dim3(256), 0, 0, bad, out);
+    unsigned hbad = 1;
+    CHK(hipMemcpy(&hbad, bad, 4, hipMemcpyDeviceToHost));
+    printf("sdwa/denormal byte product: %u mismatches of %u\n", hbad, 256u * 256u * 256u);
     return 0;
 }

@@ -43,6 +43,41 @@ static void gaussian_kernel_f32(int n, double sigma, float* cf) {
     for (int i = 0; i < n; i++) cf[i] = (float)(cf[i] * sum);
 }
 
+// Box corners of one layer (SURVEY A.2): cvRound(size/9 * v).  size*v/9 is never within 1/18 of a tie, so the
+// integer form below equals the float rounding of the reference; vo_build_detect_tables checks that.
+struct BoxGeom {
+    int ex[4];   // R(0), R(3), R(6), R(9): x edges of Dxx boxes = y edges of Dyy boxes
+    int e27[2];  // R(2), R(7)
+    int c[4];    // R(1), R(4), R(5), R(8): Dxy corners
+};
+constexpr int box_round(int size, int v) { return (2 * size * v + 9) / 18; }
+constexpr BoxGeom box_geom(int size) {
+    return BoxGeom{{box_round(size, 0), box_round(size, 3), box_round(size, 6), box_round(size, 9)},
+                   {box_round(size, 2), box_round(size, 7)},
+                   {box_round(size, 1), box_round(size, 4), box_round(size, 5), box_round(size, 8)}};
+}
+
+// The ten box weights of a layer, w = sign / ((float)(dx2 - dx1) * (dy2 - dy1)) as vo_build_detect_tables computes them (which
+// checks that the two agree).  Compile-time for the LDS-tile kernels: a weight is then a literal operand of its multiply - at the
+// FP32 rate, where an SGPR operand halves it - and, what matters more, no scalar load of the constant table sits in the det
+// loop: scalar loads and LDS reads share one wait counter, and every s_waitcnt for a weight drained the taps in flight.
+struct BoxWeights {
+    float w[10];
+};
+constexpr BoxWeights box_weights(int size) {
+    const BoxGeom G = box_geom(size);
+    BoxWeights r{};
+    const float wsgn[3] = {1, -2, 1};
+    for (int k = 0; k < 3; k++) {
+        r.w[k] = wsgn[k] / ((float)(G.ex[k + 1] - G.ex[k]) * (float)(G.e27[1] - G.e27[0]));
+        r.w[3 + k] = wsgn[k] / ((float)(G.e27[1] - G.e27[0]) * (float)(G.ex[k + 1] - G.ex[k]));
+    }
+    const int bx[4] = {0, 2, 0, 2}, by[4] = {0, 0, 2, 2};
+    const float ws[4] = {1, -1, -1, 1};
+    for (int k = 0; k < 4; k++) r.w[6 + k] = ws[k] / ((float)(G.c[bx[k] + 1] - G.c[bx[k]]) * (float)(G.c[by[k] + 1] - G.c[by[k]]));
+    return r;
+}
+
 void vo_build_detect_tables(DetectTables& t, int) {
     std::memset(&t, 0, sizeof(t));
     for (int o = 0; o < kNumOctaves; o++)
@@ -83,6 +118,11 @@ void vo_build_detect_tables(DetectTables& t, int) {
             const float ws[4] = {1, -1, -1, 1};
             for (int k = 0; k < 4; k++)
                 L.w[6 + k] = ws[k] / ((float)(c[bx[k] + 1] - c[bx[k]]) * (c[by[k] + 1] - c[by[k]]));
+            const BoxWeights cw = box_weights(L.size);  // what the LDS-tile kernels use as literals
+            if (std::memcmp(cw.w, L.w, sizeof(cw.w)) != 0) {
+                std::fprintf(stderr, "vo_mi355x: box weight table mismatch (size %d)\n", L.size);
+                std::abort();
+            }
         }
     float G_ori[13];
     gaussian_kernel_f32(13, 2.5, G_ori);
@@ -133,20 +173,6 @@ __device__ __forceinline__ float d_fastAtan2(float y, float x) {
     if (x < 0) a = 180.f - a;
     if (y < 0) a = 360.f - a;
     return a;
-}
-
-// Box corners of one layer (SURVEY A.2): cvRound(size/9 * v).  size*v/9 is never within 1/18 of a tie, so the
-// integer form below equals the float rounding of the reference; vo_build_detect_tables checks that.
-struct BoxGeom {
-    int ex[4];   // R(0), R(3), R(6), R(9): x edges of Dxx boxes = y edges of Dyy boxes
-    int e27[2];  // R(2), R(7)
-    int c[4];    // R(1), R(4), R(5), R(8): Dxy corners
-};
-constexpr int box_round(int size, int v) { return (2 * size * v + 9) / 18; }
-constexpr BoxGeom box_geom(int size) {
-    return BoxGeom{{box_round(size, 0), box_round(size, 3), box_round(size, 6), box_round(size, 9)},
-                   {box_round(size, 2), box_round(size, 7)},
-                   {box_round(size, 1), box_round(size, 4), box_round(size, 5), box_round(size, 8)}};
 }
 
 // Dx, Dy, Dxy of one layer at one sample.  tap(y, x) returns the integral image at offset (y, x) from the
@@ -790,6 +816,29 @@ struct LdsTileCfg {
     static constexpr int kBytes = kSumBytes > kOverlayBytes ? kSumBytes : kOverlayBytes;
 };
 
+// Sample s of a tile -> (row, column) for the det phase.  A tap is one ds_read_b32 per lane: the LDS serves lanes 0-31 and 32-63
+// in one cycle each when the 32 words lie in 32 different banks (word address mod 32).  Octave 0: a tile row is 32 consecutive
+// words - row-major order is conflict-free.  Octave 1 (24-sample rows, row pitch 2 * PP = 236 = 12 mod 32): row-major order puts
+// lanes 24-31 (the next row) on banks 12-19 again, every tap took two cycles per group (SQ_LDS_BANK_CONFLICT = 47 % of
+// SQ_LDS_IDX_ACTIVE); blocks of 8 rows x 4 columns per 32 lanes land on bank offsets 0,12,24,4,16,28,8,20 (+0..3): all 32 distinct.
+template <int T, int O>
+struct DetOrder {
+    static constexpr bool kBlocked = O == 1;
+    static __device__ __forceinline__ void pos(int s, int& yy, int& xx) {
+        if constexpr (kBlocked) {
+            static_assert(O == 0 || (T % 8 == 0 && (2 * LdsTileCfg<T, O>::PP) % 32 == 12), "8 x 4 blocks are conflict-free for this pitch only");
+            const int g = s >> 5, l = s & 31;
+            constexpr int kColBlocks = T / 4;
+            const int rb = g / kColBlocks, cb = g - rb * kColBlocks;
+            yy = rb * 8 + (l >> 2);
+            xx = cb * 4 + (l & 3);
+        } else {
+            yy = s / T;
+            xx = s - yy * T;
+        }
+    }
+};
+
 template <int T, int O, int NTH>
 __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b, int frame,
                                                      const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
@@ -841,21 +890,22 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     // det of sample s of layer l; the box corners are compile-time constants: every tap is a ds_read with an immediate offset
     auto det_at = [&](auto lc, int s) -> float {
         constexpr int l = decltype(lc)::value;
-        const LayerTab& L = c_tab.layers[O * kLayersPerOctave + l];
         constexpr int lsize = (9 + 6 * l) << O;
         constexpr BoxGeom G = box_geom(lsize);
+        constexpr BoxWeights WG = box_weights(lsize);
         constexpr int lmargin = (lsize / 2) / step;
         const bool fits = (lsize <= H && lsize <= W);
         const int samples_i = fits ? 1 + (H - lsize) / step : 0;
         const int samples_j = fits ? 1 + (W - lsize) / step : 0;
         constexpr int dm = kMarginMax - lmargin;
-        const int yy = s / T, xx = s - yy * T;
+        int yy, xx;
+        DetOrder<T, O>::pos(s, yy, xx);
         const int oi = i0 + yy - lmargin, oj = j0 + xx - lmargin;
         float dv = 0.f;
         if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
             float dx, dy, dxy;
             const LdsTap<O, PP, HALF> tap{(const __attribute__((address_space(3))) int32_t*)s_sum + (yy + dm) * step * PP + (xx + dm)};
-            hessian_boxes_t(G, L.w, tap, dx, dy, dxy);
+            hessian_boxes_t(G, WG.w, tap, dx, dy, dxy);
             dv = hessian_det(dx, dy, dxy);
         }
         return dv;
@@ -893,11 +943,16 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     __syncthreads();  // every tap has been read: the patch is dead, the det planes take its place
 #pragma unroll
     for (int it = 0; it < kRounds; it++) {
-        const int s = tid + it * NTH, yy = s / T, xx = s - yy * T;
+        int yy, xx;
+        DetOrder<T, O>::pos(tid + it * NTH, yy, xx);
 #pragma unroll
         for (int l = 0; l < kLayersPerOctave; l++) s_det[l][yy][xx] = dvr[it][l];
     }
-    if (has_rem) s_det[wv_rem][s_rem / T][s_rem % T] = dv_rem;
+    if (has_rem) {
+        int yy, xx;
+        DetOrder<T, O>::pos(s_rem, yy, xx);
+        s_det[wv_rem][yy][xx] = dv_rem;
+    }
     __syncthreads();
 
     // the candidate queue sits behind the det planes
