@@ -151,6 +151,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     const int nbands = (H + 15) / 16;
     VO_TRY(dalloc(fs.img, (size_t)F * H * W + 256));  // tile staging may read up to 111 bytes past a row end
     VO_TRY(dalloc(fs.sum, (size_t)F * (H + 1) * (W + 1) + 64));
+    VO_TRY(dalloc(fs.sum4, (size_t)F * fs.sum4_stride() + 64));
     VO_TRY(dalloc(fs.colsum, (size_t)F * nbands * W));
     VO_TRY(dalloc(fs.quad, (size_t)F * ((W + 7) / 8) * 8 * H + 64));  // 8-pixel column strips (vo_detect.hip, quad_index)
     VO_TRY(dalloc(fs.kp_raw, (size_t)F * cap));
@@ -173,6 +174,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
 void vo_frameset_free(FrameSet& fs) {
     dfree(fs.img);
     dfree(fs.sum);
+    dfree(fs.sum4);
     dfree(fs.colsum);
     dfree(fs.quad);
     dfree(fs.kp_raw);

@@ -134,6 +134,7 @@ struct FrameSet {
     int F = 0, H = 0, W = 0, cap = 0;
     uint8_t* img = nullptr;      // [F][H][W]
     int32_t* sum = nullptr;      // [F][H+1][W+1]
+    int32_t* sum4 = nullptr;     // [F][4][H+1][sum4_pitch] the same values by column phase: sum[y][x] at plane x & 3, word x >> 2 (coarse octaves)
     int32_t* colsum = nullptr;   // [F][nbands][W]
     uint32_t* quad = nullptr;    // [F][ceil(W/8)][H][8] bilinear footprints p(y,x) | p(y,x+1)<<8 | p(y+1,x)<<16 | p(y+1,x+1)<<24 in 8-pixel column strips
     vo_keypoint* kp_raw = nullptr;  // [F][cap]
@@ -151,6 +152,9 @@ struct FrameSet {
     int nbins() const { return ((W + 255) / 256) * ((H + 255) / 256); }
     size_t img_stride() const { return (size_t)H * W; }
     size_t sum_stride() const { return (size_t)(H + 1) * (W + 1); }
+    int sum4_pitch() const { return ((W + 1 + 3) / 4 + 31) & ~31; }  // words per plane row: whole 128-byte lines
+    size_t sum4_plane() const { return (size_t)(H + 1) * sum4_pitch(); }
+    size_t sum4_stride() const { return 4 * sum4_plane(); }
 };
 
 struct PairSet {

@@ -230,6 +230,27 @@ __device__ __forceinline__ void hessian_boxes(const LayerTab& L, const int32_t* 
     hessian_boxes_t(G, L.w, GlobalTap{org, sw}, dx, dy, dxy);
 }
 
+// Column-phase planes of the integral image (k_sum_planes): sum[y][x] at plane x & 3, row y, word x >> 2.  Octave o >= 2 samples
+// every 4th / 8th pixel: for one box corner the lanes of a tile row read words that are 1 / 2 apart in ONE plane - two or four
+// cache lines per wavefront load where the row-major image gives eight or sixteen (a quarter / an eighth of each used), which
+// is what bounded those tiles (L2 -> L1 line fills).  `lane` points at plane 0, row = the sample's box origin row, word = origin
+// column / 4 (a multiple of 4); the rest of a tap's address is the same in every lane.
+struct PlanarTap {
+    const int32_t* __restrict__ plane0;
+    uint32_t lane;  // BYTE offset of this lane's box origin (a frame's planes are < 4 GB): scalar base + 32-bit vector offset
+    int pw;         // words per plane row
+    size_t ps;      // words per plane
+    __device__ __forceinline__ uint32_t operator()(int y, int x) const {
+        const int32_t* __restrict__ u = plane0 + ((size_t)(x & 3) * ps + (size_t)y * pw + (x >> 2));
+        return *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(u) + lane);
+    }
+};
+
+__device__ __forceinline__ void hessian_boxes_planar(const LayerTab& L, const PlanarTap& tap, float& dx, float& dy, float& dxy) {
+    const BoxGeom G{{L.xdx[0], L.xdx[1], L.xdx[2], L.xdx[3]}, {L.ydx[0], L.ydx[1]}, {L.cxy[0], L.cxy[1], L.cxy[2], L.cxy[3]}};
+    hessian_boxes_t(G, L.w, tap, dx, dy, dxy);
+}
+
 __device__ __forceinline__ float hessian_det(float dx, float dy, float dxy) {
     float t1 = dx * dy;
     float t2 = 0.81f * dxy;
@@ -389,7 +410,8 @@ struct __attribute__((packed, aligned(4))) Int4U {  // four consecutive ints at 
 // it in column chunks, the row sums carried from chunk to chunk.
 template <int NT, bool MULTI>
 __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_integral4(const uint8_t* __restrict__ img, size_t img_stride, int H, int W, int nbands,
-                                                  const int32_t* __restrict__ colsum, int32_t* __restrict__ sum, size_t sum_stride) {
+                                                  const int32_t* __restrict__ colsum, int32_t* __restrict__ sum, size_t sum_stride,
+                                                  int32_t* __restrict__ sum4, int pw, size_t ps) {
     constexpr int NWV = NT / 64;
     __shared__ int32_t s_wtot[kBand][NWV + 1];  // per row: the wavefronts' totals, then (after the second-level scan) their
                                                 // exclusive prefixes and, in the last slot, the row's chunk total
@@ -399,9 +421,13 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     const int sw = W + 1;
     const uint8_t* im = img + (size_t)frame * img_stride;
     int32_t* out = sum + (size_t)frame * sum_stride;
+    // the same values a second time, by column phase (PlanarTap): the lane's four columns x + 1 .. x + 4 go to planes 1, 2, 3, 0
+    int32_t* out4 = sum4 + (size_t)frame * 4 * ps;
     const int32_t* cs = colsum + ((size_t)frame * nbands + band) * W;
-    if (band == 0)
+    if (band == 0) {
         for (int x = tid; x < sw; x += NT) out[x] = 0;
+        for (int x = tid; x < 4 * pw; x += NT) out4[(size_t)(x / pw) * ps + (x % pw)] = 0;
+    }
     int32_t chunk_carry[MULTI ? kBand : 1];  // sum of the row's pixels left of the current chunk (frames wider than NT * 4)
 #pragma unroll
     for (int r = 0; r < (MULTI ? kBand : 1); r++) chunk_carry[r] = 0;
@@ -460,7 +486,8 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void
             }
             if (y < H) {
                 int32_t* row = out + (size_t)(y + 1) * sw;
-                if (xc == 0 && tid == 0) row[0] = 0;
+                int32_t* row4 = out4 + (size_t)(y + 1) * pw + (x >> 2);
+                if (xc == 0 && tid == 0) row[0] = 0, row4[0] = 0;
                 if (live) {
                     Int4U o;
                     o.v[0] = carry.x + off;
@@ -468,6 +495,10 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void
                     o.v[2] = o.v[1] + carry.z;
                     o.v[3] = o.v[2] + carry.w;
                     *reinterpret_cast<Int4U*>(row + x + 1) = o;
+                    row4[ps] = o.v[0];
+                    row4[2 * ps] = o.v[1];
+                    row4[3 * ps] = o.v[2];
+                    row4[1] = o.v[3];
                 }
             }
         }
@@ -475,7 +506,40 @@ __global__ __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(5, 8))) void
     }
 }
 
+// Column-phase copy of the integral image for the coarse octaves (PlanarTap): plane p of a frame holds columns p, p + 4, ...
+__global__ __launch_bounds__(256) void k_sum_planes(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+                                                    int32_t* __restrict__ out_base, int pw, size_t ps) {
+    const int y = blockIdx.y, f = blockIdx.z, jj = blockIdx.x * 256 + threadIdx.x;
+    const int sw = W + 1;
+    if (4 * jj > W) return;
+    const int32_t* __restrict__ row = sum_base + (size_t)f * sum_stride + (size_t)y * sw;
+    int32_t v[4];
+    if (4 * jj + 3 <= W) {
+        const Int4U q = *reinterpret_cast<const Int4U*>(row + 4 * jj);
+        v[0] = q.v[0], v[1] = q.v[1], v[2] = q.v[2], v[3] = q.v[3];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) v[k] = 4 * jj + k <= W ? row[4 * jj + k] : 0;
+    }
+    int32_t* __restrict__ out = out_base + (size_t)f * 4 * ps + (size_t)y * pw + jj;
+#pragma unroll
+    for (int k = 0; k < 4; k++) out[(size_t)k * ps] = v[k];
+}
+
+static int enqueue_integral_rows(vo_ctx* ctx, FrameSet& fs, hipStream_t stream);
+
 int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs, hipStream_t stream) {
+    VO_TRY(enqueue_integral_rows(ctx, fs, stream));
+    if (fs.W % 4 == 0 && fs.img_stride() % 4 == 0) return VO_OK;  // k_integral4 wrote the planes itself
+    StageScope sc(ctx, ST_INTEGRAL, stream);
+    const int pw = fs.sum4_pitch();
+    hipLaunchKernelGGL(k_sum_planes, dim3(((fs.W + 4) / 4 + 255) / 256, fs.H + 1, fs.F), dim3(256), 0, stream, fs.sum, fs.sum_stride(), fs.H,
+                       fs.W, fs.sum4, pw, fs.sum4_plane());
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+static int enqueue_integral_rows(vo_ctx* ctx, FrameSet& fs, hipStream_t stream) {
     StageScope sc(ctx, ST_INTEGRAL, stream);
     const int nbands = (fs.H + kBand - 1) / kBand;
     dim3 g1((fs.W + 255) / 256, nbands, fs.F);
@@ -490,13 +554,13 @@ int vo_enqueue_integral(vo_ctx* ctx, FrameSet& fs, hipStream_t stream) {
     if (aligned4) {
         if (fs.W <= 1024)
             hipLaunchKernelGGL((k_integral4<256, false>), g2, dim3(256), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
-                               fs.sum, fs.sum_stride());
+                               fs.sum, fs.sum_stride(), fs.sum4, fs.sum4_pitch(), fs.sum4_plane());
         else if (fs.W <= 2048)
             hipLaunchKernelGGL((k_integral4<512, false>), g2, dim3(512), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
-                               fs.sum, fs.sum_stride());
+                               fs.sum, fs.sum_stride(), fs.sum4, fs.sum4_pitch(), fs.sum4_plane());
         else
             hipLaunchKernelGGL((k_integral4<512, true>), g2, dim3(512), 0, stream, fs.img, fs.img_stride(), fs.H, fs.W, nbands, fs.colsum,
-                               fs.sum, fs.sum_stride());
+                               fs.sum, fs.sum_stride(), fs.sum4, fs.sum4_pitch(), fs.sum4_plane());
         VO_HIP(hipGetLastError());
         return VO_OK;
     }
@@ -743,6 +807,7 @@ constexpr int kGlobalTileLds = kGlobalTileDet + (kNmsQueue + 1) * 4;
 
 __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int b, int frame,
                                                         const int32_t* __restrict__ sum_base, size_t sum_stride,
+                                                        const int32_t* __restrict__ sum4_base, int pw, size_t ps,
                                                         const DetectGeom& g, float thr, vo_keypoint* __restrict__ kp_base,
                                                         int cap, FrameCounters* __restrict__ cnt, int filter_invalid,
                                                         float* __restrict__ dbg_det) {
@@ -753,10 +818,11 @@ __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int
         if (b >= g.tile_base[q]) o = q;
     b -= g.tile_base[o];
     const int ty = b / g.tiles_x[o], tx = b - ty * g.tiles_x[o];
-    const int H = g.H, W = g.W, sw = W + 1;
+    const int H = g.H, W = g.W;
     const int step = 1 << o;
     (void)0;
     const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
+    const int32_t* __restrict__ planes = sum4_base + (size_t)frame * 4 * ps;
     const int tid = threadIdx.x;
     const int i0 = ty * kTY - 1, j0 = tx * kTX - 1;
 
@@ -771,7 +837,8 @@ __device__ __forceinline__ void hessian_nms_global_tile(unsigned char* smem, int
             float dv = 0.f;
             if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
                 float dx, dy, dxy;
-                hessian_boxes(L, sum + (size_t)(oi * step) * sw + oj * step, sw, dx, dy, dxy);
+                // (step is 4 or 8 here: the origin column oj * step is a multiple of 4)
+                hessian_boxes_planar(L, PlanarTap{planes, 4u * ((uint32_t)(oi * step) * (uint32_t)pw + (uint32_t)((oj * step) >> 2)), pw, ps}, dx, dy, dxy);
                 dv = hessian_det(dx, dy, dxy);
             }
             s_det[l][yy][xx] = dv;
@@ -963,7 +1030,8 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
 // octave-0 tiles (LDS patch) and the few tiles of octaves >= OG (taps from L1/L2) in ONE grid, so that the long,
 // latency-bound workgroups of the coarse octaves overlap the bulk of the work
 template <int T0, int NTH>
-__global__ __launch_bounds__(NTH) void k_hessian_nms_fused(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
+__global__ __launch_bounds__(NTH) void k_hessian_nms_fused(const int32_t* __restrict__ sum_base, size_t sum_stride,
+                                                           const int32_t* __restrict__ sum4_base, int pw, size_t ps, int H, int W,
                                                            int tiles_x0, int n_tiles0, DetectGeom g_rest, float thr,
                                                            vo_keypoint* __restrict__ kp_base, int cap,
                                                            FrameCounters* __restrict__ cnt, int filter_invalid,
@@ -974,7 +1042,7 @@ __global__ __launch_bounds__(NTH) void k_hessian_nms_fused(const int32_t* __rest
     // coarse tiles first in the grid: they are the long ones
     const int n_rest = g_rest.tile_base[kNumOctaves];
     if (b < n_rest)
-        hessian_nms_global_tile(smem, b, frame, sum_base, sum_stride, g_rest, thr, kp_base, cap, cnt, filter_invalid, dbg_det);
+        hessian_nms_global_tile(smem, b, frame, sum_base, sum_stride, sum4_base, pw, ps, g_rest, thr, kp_base, cap, cnt, filter_invalid, dbg_det);
     else
         hessian_nms_lds_tile<T0, 0, NTH>(smem, b - n_rest, frame, sum_base, sum_stride, H, W, tiles_x0, thr, kp_base, cap, cnt,
                                     filter_invalid, dbg_det);
@@ -2349,7 +2417,7 @@ int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_
             StageScope sc0(ctx, ST_HESSIAN_OCT0);
             const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
             hipLaunchKernelGGL((k_hessian_nms_fused<T0, 256>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
-                               fs.sum_stride(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
+                               fs.sum_stride(), fs.sum4, fs.sum4_pitch(), fs.sum4_plane(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
                                describe ? 1 : 0, dbg_det);
         }
         if (beside) {
