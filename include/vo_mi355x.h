@@ -68,10 +68,11 @@ typedef enum vo_fail { VO_FAIL_DETECTION = 0, VO_NOT_MOVING = 1, VO_FAIL_RECOVER
  */
 typedef struct vo_params {
     float hessian_threshold;      /* minHessian = 50                       :33 */
-    int32_t n_octaves;            /* 4                                     :35 */
-    int32_t n_octave_layers;      /* 3                                     :36 */
-    int32_t extended;             /* false (64 floats)                     :37 */
-    int32_t upright;              /* false                                 :38 */
+    int32_t n_octaves;            /* 4 (1..4 accepted)                     :35 */
+    int32_t n_octave_layers;      /* 3 (other values: VO_ERR_UNSUPPORTED)  :36 */
+    int32_t extended;             /* false (64 floats; true: UNSUPPORTED)  :37 */
+    int32_t upright;              /* false (true accepted: angle 270,      :38
+                                     axis-aligned windows, sequential kernel) */
     float ratio_thresh;           /* 0.7f                                  :41 */
     float roi_x_lo, roi_y_lo;     /* width_low = 28, height_low = 20       :44-45 */
     float roi_x_hi, roi_y_hi;     /* width_high = 614, height_high = 482   :46-47 */

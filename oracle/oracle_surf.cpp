@@ -153,9 +153,10 @@ static bool keypointGreater(const vo_keypoint& a, const vo_keypoint& b) {
     return a.x < b.x;
 }
 
-// fastHessianDetector (A.2-A.4), nOctaves=4, nOctaveLayers=3
-void fast_hessian(const int32_t* sum, int rows, int cols, float hessianThreshold, std::vector<vo_keypoint>& kps) {
-    const int nOctaves = 4, nOctaveLayers = 3;
+// fastHessianDetector (A.2-A.4), nOctaveLayers=3; nOctaves is the reference's 4 unless the caller asks for fewer (the octaves
+// are independent of each other: fewer octaves = the same keypoints without those of the dropped octaves)
+void fast_hessian(const int32_t* sum, int rows, int cols, float hessianThreshold, std::vector<vo_keypoint>& kps, int nOctaves) {
+    const int nOctaveLayers = 3;
     const int nTotal = (nOctaveLayers + 2) * nOctaves;
     std::vector<std::vector<float>> dets(nTotal), traces(nTotal);
     std::vector<int> sizes(nTotal), steps(nTotal);
@@ -389,8 +390,11 @@ struct InvokerTables {
 };
 
 // One keypoint of SURFInvoker::operator().  Returns false if the keypoint is deleted.
+// upright (SURF's `upright` flag, false in the reference, camera_utility.hpp:38): no orientation search - the angle is 270 and the
+// window is an axis-aligned pixel rectangle.  That branch is NOT part of SURVEY Appendix A; it restates the published OpenCV source
+// (xfeatures2d surf.cpp, SURFInvoker) and nothing in the reference exercises it: parity unpinned like the rest, one step further.
 static bool describe_one(const InvokerTables& T, const uint8_t* img, size_t imgstep, int rows, int cols,
-                         const int32_t* sum, vo_keypoint& kp, float* vec /*64 or null*/, std::vector<uint8_t>& winbuf) {
+                         const int32_t* sum, vo_keypoint& kp, float* vec /*64 or null*/, std::vector<uint8_t>& winbuf, bool upright) {
     const int sw = cols + 1;
     const int sum_rows = rows + 1, sum_cols = cols + 1;
     static const int dx_s[2][5] = {{0, 0, 2, 4, -1}, {2, 0, 4, 4, 1}};
@@ -401,41 +405,44 @@ static bool describe_one(const InvokerTables& T, const uint8_t* img, size_t imgs
     float s = size * 1.2f / 9.0f;
     int grad_wav_size = 2 * cvRoundF(2 * s);
     if (sum_rows < grad_wav_size || sum_cols < grad_wav_size) return false;
-    SurfHF dx_t[2], dy_t[2];
-    resizeHaarPattern(dx_s, dx_t, 2, 4, grad_wav_size, sw);
-    resizeHaarPattern(dy_s, dy_t, 2, 4, grad_wav_size, sw);
-    int nangle = 0;
-    for (int kk = 0; kk < T.nOriSamples; kk++) {
-        int x = cvRoundF(cx + T.aptx[kk] * s - (float)(grad_wav_size - 1) / 2);
-        int y = cvRoundF(cy + T.apty[kk] * s - (float)(grad_wav_size - 1) / 2);
-        if (y < 0 || y >= sum_rows - grad_wav_size || x < 0 || x >= sum_cols - grad_wav_size) continue;
-        const int32_t* ptr = sum + (size_t)y * sw + x;
-        float vx = calcHaarPattern(ptr, dx_t, 2);
-        float vy = calcHaarPattern(ptr, dy_t, 2);
-        X[nangle] = vx * T.aptw[kk];
-        Y[nangle] = vy * T.aptw[kk];
-        nangle++;
-    }
-    if (nangle == 0) return false;
-    for (int j = 0; j < nangle; j++) angle[j] = fastAtan2(Y[j], X[j]);  // cv::phase(X, Y, angle, true)
-    float bestx = 0, besty = 0, descriptor_mod = 0;
-    for (int i = 0; i < 360; i += SURF_ORI_SEARCH_INC) {
-        float sumx = 0, sumy = 0, temp_mod;
-        for (int j = 0; j < nangle; j++) {
-            int d = std::abs(cvRoundF(angle[j]) - i);
-            if (d < ORI_WIN / 2 || d > 360 - ORI_WIN / 2) {
-                sumx += X[j];
-                sumy += Y[j];
+    float descriptor_dir = 360.f - 90.f;
+    if (!upright) {
+        SurfHF dx_t[2], dy_t[2];
+        resizeHaarPattern(dx_s, dx_t, 2, 4, grad_wav_size, sw);
+        resizeHaarPattern(dy_s, dy_t, 2, 4, grad_wav_size, sw);
+        int nangle = 0;
+        for (int kk = 0; kk < T.nOriSamples; kk++) {
+            int x = cvRoundF(cx + T.aptx[kk] * s - (float)(grad_wav_size - 1) / 2);
+            int y = cvRoundF(cy + T.apty[kk] * s - (float)(grad_wav_size - 1) / 2);
+            if (y < 0 || y >= sum_rows - grad_wav_size || x < 0 || x >= sum_cols - grad_wav_size) continue;
+            const int32_t* ptr = sum + (size_t)y * sw + x;
+            float vx = calcHaarPattern(ptr, dx_t, 2);
+            float vy = calcHaarPattern(ptr, dy_t, 2);
+            X[nangle] = vx * T.aptw[kk];
+            Y[nangle] = vy * T.aptw[kk];
+            nangle++;
+        }
+        if (nangle == 0) return false;
+        for (int j = 0; j < nangle; j++) angle[j] = fastAtan2(Y[j], X[j]);  // cv::phase(X, Y, angle, true)
+        float bestx = 0, besty = 0, descriptor_mod = 0;
+        for (int i = 0; i < 360; i += SURF_ORI_SEARCH_INC) {
+            float sumx = 0, sumy = 0, temp_mod;
+            for (int j = 0; j < nangle; j++) {
+                int d = std::abs(cvRoundF(angle[j]) - i);
+                if (d < ORI_WIN / 2 || d > 360 - ORI_WIN / 2) {
+                    sumx += X[j];
+                    sumy += Y[j];
+                }
+            }
+            temp_mod = sumx * sumx + sumy * sumy;
+            if (temp_mod > descriptor_mod) {
+                descriptor_mod = temp_mod;
+                bestx = sumx;
+                besty = sumy;
             }
         }
-        temp_mod = sumx * sumx + sumy * sumy;
-        if (temp_mod > descriptor_mod) {
-            descriptor_mod = temp_mod;
-            bestx = sumx;
-            besty = sumy;
-        }
+        descriptor_dir = fastAtan2(-besty, bestx);
     }
-    float descriptor_dir = fastAtan2(-besty, bestx);
     kp.angle = descriptor_dir;
     if (!vec) return true;
 
@@ -443,29 +450,44 @@ static bool describe_one(const InvokerTables& T, const uint8_t* img, size_t imgs
     int win_size = (int)((PATCH_SZ + 1) * s);
     if ((int)winbuf.size() < win_size * win_size) winbuf.resize((size_t)win_size * win_size);
     uint8_t* WIN = winbuf.data();
-    descriptor_dir *= (float)(3.1415926535897932384626433832795 / 180);
-    // std::sin/std::cos(float) of the reference's libm; the oracle DEFINES them as the
-    // double-precision function rounded to float (correctly rounded but for double-rounding
-    // corner cases), so that the GPU can reproduce the value bit-for-bit.
-    float sin_dir = -(float)std::sin((double)descriptor_dir);
-    float cos_dir = (float)std::cos((double)descriptor_dir);
-    float win_offset = -(float)(win_size - 1) / 2;
-    float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
-    float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
-    int ncols1 = cols - 1, nrows1 = rows - 1;
-    for (int i = 0; i < win_size; i++, start_x += sin_dir, start_y += cos_dir) {
-        double pixel_x = start_x;
-        double pixel_y = start_y;
-        for (int j = 0; j < win_size; j++, pixel_x += cos_dir, pixel_y -= sin_dir) {
-            int ix = cvFloor(pixel_x), iy = cvFloor(pixel_y);
-            if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
-                float a = (float)(pixel_x - ix), b = (float)(pixel_y - iy);
-                const uint8_t* p = img + (size_t)iy * imgstep + ix;
-                WIN[i * win_size + j] = (uint8_t)cvRoundF(p[0] * (1.f - a) * (1.f - b) + p[1] * a * (1.f - b) +
-                                                          p[imgstep] * (1.f - a) * b + p[imgstep + 1] * a * b);
-            } else {
-                int x = std::min(std::max(cvRound(pixel_x), 0), ncols1);
-                int y = std::min(std::max(cvRound(pixel_y), 0), nrows1);
+    if (!upright) {
+        descriptor_dir *= (float)(3.1415926535897932384626433832795 / 180);
+        // std::sin/std::cos(float) of the reference's libm; the oracle DEFINES them as the
+        // double-precision function rounded to float (correctly rounded but for double-rounding
+        // corner cases), so that the GPU can reproduce the value bit-for-bit.
+        float sin_dir = -(float)std::sin((double)descriptor_dir);
+        float cos_dir = (float)std::cos((double)descriptor_dir);
+        float win_offset = -(float)(win_size - 1) / 2;
+        float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
+        float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
+        int ncols1 = cols - 1, nrows1 = rows - 1;
+        for (int i = 0; i < win_size; i++, start_x += sin_dir, start_y += cos_dir) {
+            double pixel_x = start_x;
+            double pixel_y = start_y;
+            for (int j = 0; j < win_size; j++, pixel_x += cos_dir, pixel_y -= sin_dir) {
+                int ix = cvFloor(pixel_x), iy = cvFloor(pixel_y);
+                if ((unsigned)ix < (unsigned)ncols1 && (unsigned)iy < (unsigned)nrows1) {
+                    float a = (float)(pixel_x - ix), b = (float)(pixel_y - iy);
+                    const uint8_t* p = img + (size_t)iy * imgstep + ix;
+                    WIN[i * win_size + j] = (uint8_t)cvRoundF(p[0] * (1.f - a) * (1.f - b) + p[1] * a * (1.f - b) +
+                                                              p[imgstep] * (1.f - a) * b + p[imgstep + 1] * a * b);
+                } else {
+                    int x = std::min(std::max(cvRound(pixel_x), 0), ncols1);
+                    int y = std::min(std::max(cvRound(pixel_y), 0), nrows1);
+                    WIN[i * win_size + j] = img[(size_t)y * imgstep + x];
+                }
+            }
+        }
+    } else {
+        // descriptor_dir == 90 degrees, sin_dir == 1, cos_dir == 0: an extract-rect with clamped borders
+        float win_offset = -(float)(win_size - 1) / 2;
+        int start_x = cvRoundF(cx + win_offset);
+        int start_y = cvRoundF(cy - win_offset);
+        for (int i = 0; i < win_size; i++, start_x++) {
+            int pixel_x = start_x, pixel_y = start_y;
+            for (int j = 0; j < win_size; j++, pixel_y--) {
+                int x = std::min(std::max(pixel_x, 0), cols - 1);
+                int y = std::min(std::max(pixel_y, 0), rows - 1);
                 WIN[i * win_size + j] = img[(size_t)y * imgstep + x];
             }
         }
@@ -507,7 +529,7 @@ void detect_describe(const vo_params& P, const uint8_t* img, int rows, int cols,
                      std::vector<vo_keypoint>& kps, std::vector<float>* desc) {
     std::vector<int32_t> sum((size_t)(rows + 1) * (cols + 1));
     integral_u8(img, rows, cols, step, sum.data());
-    fast_hessian(sum.data(), rows, cols, P.hessian_threshold, kps);
+    fast_hessian(sum.data(), rows, cols, P.hessian_threshold, kps, P.n_octaves);
     if (!desc) return;
     static const InvokerTables T;
     const int N = (int)kps.size();
@@ -518,7 +540,7 @@ void detect_describe(const vo_params& P, const uint8_t* img, int rows, int cols,
         std::vector<uint8_t> winbuf;
 #pragma omp for schedule(dynamic, 16)
         for (int k = 0; k < N; k++)
-            keep[k] = describe_one(T, img, step, rows, cols, sum.data(), kps[k], d.data() + (size_t)k * 64, winbuf);
+            keep[k] = describe_one(T, img, step, rows, cols, sum.data(), kps[k], d.data() + (size_t)k * 64, winbuf, P.upright != 0);
     }
     // step 5: drop deleted keypoints preserving order
     int w = 0;

@@ -197,3 +197,47 @@ def test_descriptor_cells_spanning_many_binades(ctx):
     nz = np.where(energy > 0, energy, np.nan)
     spread = np.log2(np.nanmax(nz.reshape(len(rd), -1), axis=1) / np.nanmin(nz.reshape(len(rd), -1), axis=1))
     assert (spread > 23).sum() >= 3 and (spread <= 23).sum() >= 3, (np.sort(spread)[-5:], len(k))  # both branches were taken
+
+
+@pytest.mark.parametrize("n_oct,upright", [(1, 0), (2, 0), (3, 0), (4, 1), (2, 1)])
+def test_surf_parameter_variants(ctx, n_oct, upright):
+    """vo_params.n_octaves < 4 and upright (camera_utility.hpp:35, :38 are mutable globals; the reference leaves them at 4 / false).
+    Fewer octaves: the octaves are independent, so the keypoints are those of the four-octave run without the dropped octaves.
+    Upright: angle 270, windows are axis-aligned pixel rectangles - restated from the published OpenCV source, outside SURVEY
+    Appendix A, nothing in the reference exercises it (parity unpinned)."""
+    from visual_odometry_amd.frontend import Context, default_params
+
+    p = default_params()
+    p.n_octaves, p.upright = n_oct, upright
+    c = Context(p)
+    try:
+        for sc in (_scene(480, 640, 700, 1001), _scene(243, 322, 150, 11)):
+            k, d = c.detect_describe(sc.img1)
+            rk, rd = O.detect_describe(sc.img1, params=p)
+            _assert_kps_equal(k, rk)
+            assert len(k) > 50 and k["octave"].max() == min(n_oct - 1, k["octave"].max())
+            assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+            assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+            if upright:
+                assert np.all(k["angle"] == 270.0)
+            else:
+                k4, d4 = ctx.detect_describe(sc.img1)
+                keep = k4["octave"] < n_oct
+                _assert_kps_equal(k, k4[keep])
+                assert np.array_equal(d.view(np.uint32), d4[keep].view(np.uint32))
+            # keypoints only (no describer: nothing is deleted)
+            k0, _ = c.detect_describe(sc.img1, describe=False)
+            rk0, _ = O.detect_describe(sc.img1, params=p, describe=False)
+            _assert_kps_equal(k0, rk0)
+    finally:
+        c.close()
+
+
+def test_unsupported_surf_variants_are_refused():
+    from visual_odometry_amd.frontend import Context, VoError, default_params
+
+    for field, value in (("n_octave_layers", 2), ("extended", 1), ("n_octaves", 5), ("n_octaves", 0)):
+        p = default_params()
+        setattr(p, field, value)
+        with pytest.raises(VoError):
+            Context(p)

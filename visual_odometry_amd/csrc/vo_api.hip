@@ -220,7 +220,9 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         p = *params;
     else
         vo_params_default(&p);
-    if (p.n_octaves != 4 || p.n_octave_layers != 3 || p.extended || p.upright) return VO_ERR_UNSUPPORTED;
+    // supported: the reference's values (4, 3, false, false); fewer octaves; upright.  Not: other layer counts, 128-float descriptors
+    if (p.n_octaves < 1 || p.n_octaves > 4 || p.n_octave_layers != 3 || p.extended) return VO_ERR_UNSUPPORTED;
+    p.upright = p.upright ? 1 : 0;
     if (p.kp_capacity < 64 || p.match_capacity < 8 || p.ransac_max_iters < 1 || p.ransac_max_iters > kMaxHyp)
         return VO_ERR_INVALID_ARG;
     p.kp_capacity = (p.kp_capacity + 63) & ~63;

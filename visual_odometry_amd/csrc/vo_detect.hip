@@ -635,10 +635,12 @@ struct DetectGeom {
 // SURFInvoker deletes a keypoint when the gradient wavelet does not fit the integral image or
 // when none of the 109 orientation samples lies inside it; the survivors keep their
 // order, so dropping such keypoints here is equivalent to A.1 step 5.
-__device__ bool kp_describable(float cx, float cy, float size, int H, int W) {
+// (upright - filter mode 2 - keeps only the first test: without an orientation search no sample has to fit)
+__device__ bool kp_describable(float cx, float cy, float size, int H, int W, bool upright) {
     const float s = size * 1.2f / 9.0f;
     const int g = 2 * d_cvRoundF(2 * s);
     if (H + 1 < g || W + 1 < g) return false;
+    if (upright) return true;
     const float half = (float)(g - 1) / 2;
     for (int kk = 0; kk < kOriSamples; kk++) {
         int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
@@ -784,7 +786,7 @@ __device__ __forceinline__ void nms_tile(const float* s_det, int* s_queue, int o
                     hessian_boxes(L, sum + (size_t)((i - L.margin) * step) * sw + (j - L.margin) * step, sw, dx, dy, dxy);
                     const float tr = dx + dy;
                     kpt.class_id = (tr > 0) - (tr < 0);
-                    emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W);
+                    emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W, filter_invalid == 2);
                 }
             }
         }
@@ -1518,6 +1520,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     // ---------------------------------------------------------------- orientation (A.5), first wavefront
     // (have_dir: k_orientation has run and the record holds the direction - the same function gave it; the integral image is
     // then not read here, so the NEXT detection's integral pass may already be overwriting it on the auxiliary stream)
+    const bool upright = have_dir == 2;  // SURF's upright flag: the window is an axis-aligned rectangle of pixels (no bilinear walk)
     if (have_dir) {
         if (tid == 0) s_dir = kpp->angle;
     } else if (tid < 64) {
@@ -1542,6 +1545,8 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     float start_x = cx + win_offset * cos_dir + win_offset * sin_dir;
     float start_y = cy - win_offset * sin_dir + win_offset * cos_dir;
     const int ncols1 = W - 1, nrows1 = H - 1;
+    // upright: WIN[i][j] = img(clamp(y0 - j), clamp(x0 + i)) with x0 = cvRound(cx + win_offset), y0 = cvRound(cy - win_offset)
+    const int up_x0 = d_cvRoundF(cx + win_offset), up_y0 = d_cvRoundF(cy - win_offset);
 
     // rows of the window: thread <-> row, columns walked sequentially so that the double coordinate
     // accumulation (pixel_x += cos_dir) is reproduced step for step, whatever the values; the row never exists as
@@ -1560,7 +1565,8 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
             float facc = 0.f;
             int iacc = 0, c = 0, left = iscale;
             for (int j = 0; j < win; j++) {
-                const int Sv = sample_pixel(img, W, ncols1, nrows1, px, py);
+                const int Sv = upright ? (int)img[(size_t)min(max(up_y0 - j, 0), nrows1) * W + min(max(up_x0 + i, 0), ncols1)]
+                                       : sample_pixel(img, W, ncols1, nrows1, px, py);
                 px += dcos;
                 py -= dsin;
                 if (area_fast) {
@@ -1740,6 +1746,12 @@ __device__ __forceinline__ void orientation_pair(const int32_t* __restrict__ sum
 
 // a5 as its own launch: two keypoints per wavefront (orientation_pair), eight per workgroup.  Keeping it out of the descriptor
 // kernel takes its registers and LDS off that kernel's budget and leaves no wavefront idle while one computes the angle.
+// upright: every keypoint's angle is 360 - 90 degrees (SURFInvoker), no orientation search
+__global__ __launch_bounds__(256) void k_upright_angle(vo_keypoint* __restrict__ kp_base, int cap, const FrameCounters* __restrict__ cnt) {
+    const int f = blockIdx.y, k = blockIdx.x * 256 + threadIdx.x;
+    if (k < min(cnt[f].n_kp, cap)) kp_base[(size_t)f * cap + k].angle = 360.f - 90.f;
+}
+
 __global__ __launch_bounds__(256) void k_orientation(const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                      vo_keypoint* __restrict__ kp_base, int cap,
                                                      const FrameCounters* __restrict__ cnt) {
@@ -2393,6 +2405,11 @@ int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_
         // (a patch would be 2-4x the tile's own taps); their few long workgroups ride in the octave-0 grid.
         DetectGeom g2 = g;
         g2.tiles_x[0] = g2.tiles_y[0] = g2.tiles_x[1] = g2.tiles_y[1] = 0;
+        // fewer than the reference's four octaves (vo_params.n_octaves): the octaves are independent, the dropped ones are not launched
+        const int n_oct = ctx->prm.n_octaves;
+        for (int o = n_oct; o < kNumOctaves; o++) g2.tiles_x[o] = g2.tiles_y[o] = 0;
+        // keypoints the describer would delete are dropped here: 1 = the reference's two tests, 2 = upright (the first test only)
+        const int filter_mode = describe ? (ctx->prm.upright ? 2 : 1) : 0;
         int base2 = 0;
         for (int o = 0; o < kNumOctaves; o++) {
             g2.tile_base[o] = base2;
@@ -2410,15 +2427,16 @@ int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_
             VO_HIP(hipStreamWaitEvent(ctx->stream_aux, ctx->ev_fork, 0));
         }
         StageScope* sc1 = new StageScope(ctx, ST_HESSIAN_OCT1);
-        hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1, 512>), dim3(tx1 * ty1, fs.F), dim3(512), 0, s_oct1, fs.sum, fs.sum_stride(),
-                           fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, describe ? 1 : 0, dbg_det);
+        if (n_oct >= 2)
+            hipLaunchKernelGGL((k_hessian_nms_lds<T1, 1, 512>), dim3(tx1 * ty1, fs.F), dim3(512), 0, s_oct1, fs.sum, fs.sum_stride(),
+                           fs.H, fs.W, tx1, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt, filter_mode, dbg_det);
         delete sc1;
         {
             StageScope sc0(ctx, ST_HESSIAN_OCT0);
             const int tx0 = (fs.W + T0 - 3) / (T0 - 2), ty0 = (fs.H + T0 - 3) / (T0 - 2);
             hipLaunchKernelGGL((k_hessian_nms_fused<T0, 256>), dim3(base2 + tx0 * ty0, fs.F), dim3(256), 0, ctx->stream, fs.sum,
                                fs.sum_stride(), fs.sum4, fs.sum4_pitch(), fs.sum4_plane(), fs.H, fs.W, tx0, tx0 * ty0, g2, ctx->prm.hessian_threshold, fs.kp_raw, fs.cap, fs.cnt,
-                               describe ? 1 : 0, dbg_det);
+                               filter_mode, dbg_det);
         }
         if (beside) {
             VO_HIP(hipEventRecord(ctx->ev_join, ctx->stream_aux));
@@ -2485,8 +2503,11 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
             const size_t ls = (size_t)fs.F * fs.cap;
             {
                 StageScope sc(ctx, ST_ORIENTATION);
-                hipLaunchKernelGGL(k_orientation, dim3((fs.cap + 7) / 8, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
-                                   fs.H, fs.W, fs.kp, fs.cap, fs.cnt);
+                if (ctx->prm.upright)
+                    hipLaunchKernelGGL(k_upright_angle, dim3((fs.cap + 255) / 256, fs.F), dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt);
+                else
+                    hipLaunchKernelGGL(k_orientation, dim3((fs.cap + 7) / 8, fs.F), dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(),
+                                       fs.H, fs.W, fs.kp, fs.cap, fs.cnt);
             }
             {
                 StageScope sc(ctx, ST_DESC_PREP);
@@ -2502,12 +2523,15 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
                 else
                     launch_quads(ctx->stream);
             }
+            // upright windows are pixel rectangles: every keypoint takes the sequential kernel, which has that branch (the flag is off
+            // in the reference, camera_utility.hpp:38: correctness only, no tiled form)
+            const int force_seq = (ctx->force_seq_describe || ctx->prm.upright) ? 1 : 0;
 #define LAUNCH_TILED(STAGE, HI, NW, RB, UMAX, G, CH, CLS, GRID, STREAM)                                                             \
     {                                                                                                                              \
         StageScope sc(ctx, STAGE);                                                                                                 \
         hipLaunchKernelGGL((k_describe_tiled<HI, NW, RB, UMAX, G, CH>), dim3(GRID), dim3((NW) * 64), 0, STREAM, fs.img,               \
                            fs.img_stride(), fs.quad, fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap,                         \
-                           fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, CLS, fs.cls_list + (size_t)4 * ls, ctx->force_seq_describe, \
+                           fs.cls_list + (size_t)(CLS) * ls, fs.cls_cnt, CLS, fs.cls_list + (size_t)4 * ls, force_seq, \
                            (const CellTab*)ctx->d_win_cell, (const PixTab*)ctx->d_win_pix, fs.dir_sc);                               \
     }
             // The heaviest class goes to a stream of its own, beside the other three: its keypoints are long (0.35 ms each), and
@@ -2532,7 +2556,8 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
                 // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
                 StageScope sc(ctx, ST_DESC_SEQ);
                 hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
-                                   fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4, 1);
+                                   fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
+                                   ctx->prm.upright ? 2 : 1);
             }
             VO_HIP(hipGetLastError());
         }
