@@ -49,6 +49,8 @@ def parse_args():
     ap.add_argument("--matcher", choices=["bf16x3", "fp32"], default="bf16x3",
                     help="matrix-core formulation of the matcher's contraction (fp32 = v_mfma_f32_32x32x2_f32, for A/B runs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="take roofline.traffic from the committed profile instead of running the two rocprofv3 --pmc passes first")
     ap.add_argument("--no-extras", action="store_true", help="headline + roofline only: skip the legs for the other BASELINE configs")
     ap.add_argument("--profile-region", action="store_true",
                     help="for rocprofv3: ONLY the per-kernel timing pass of the headline workload (every kernel alone on the main "
@@ -113,10 +115,60 @@ def make_inputs(args, rank, world, extras):
     return c2, c1, c3, workers, time.perf_counter() - t0
 
 
+def live_traffic(args):
+    """HBM-side bytes per kernel launch of THIS workload on THIS machine: FETCH_SIZE and WRITE_SIZE in two separate
+    `rocprofv3 --pmc` passes (MI355X_MICROARCH.md, HBM / rocprofv3 section) over `bench.py --profile-region`, run as child
+    processes BEFORE this process touches the GPU.  Returns ({kernel name: bytes per launch}, note) or (None, why not)."""
+    import csv
+    import glob
+    import re
+    import shutil
+    import statistics
+    import subprocess
+    import tempfile
+
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if exe is None:
+        return None, "rocprofv3 not found"
+    out = tempfile.mkdtemp(prefix="vo_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    acc = {}
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(out, ctr)
+            cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+                   "--profile-region", "--steps", "2", "--batch", str(args.batch), "--scenes", str(args.scenes), "--matcher", args.matcher]
+            try:
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, f"rocprofv3 --pmc {ctr} pass timed out"
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass exited with {r.returncode}"
+            vals = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if row["Counter_Name"] == ctr:
+                        name = re.sub(r"\(.*", "", row["Kernel_Name"]).replace("void ", "")
+                        vals.setdefault(name, []).append(float(row["Counter_Value"]))
+            if not vals:
+                return None, f"rocprofv3 --pmc {ctr} pass produced no counters"
+            acc[ctr] = {k: statistics.median(v) for k, v in vals.items()}
+    finally:
+        shutil.rmtree(out, ignore_errors=True)
+    # KB units; FETCH_SIZE doubled: the guide's gfx950 correction for wide reads (uncalibrated for the gathers of these kernels)
+    return ({k: (2.0 * f + acc["WRITE_SIZE"].get(k, 0.0)) * 1024.0 for k, f in acc["FETCH_SIZE"].items()},
+            "two rocprofv3 --pmc passes (FETCH_SIZE; WRITE_SIZE) of `bench.py --profile-region --steps 2` run by this bench before its timed "
+            "loop: median over launches, (2*FETCH_SIZE + WRITE_SIZE) KB")
+
+
 def main():
     args = parse_args()
     if args.gpus > 1 and "RANK" not in os.environ:
         sys.exit(launch_ranks(args))
+    live, live_note = None, "not requested"
+    if ("RANK" not in os.environ and not args.profile_region and not args.no_live_traffic and not args.no_extras
+            and args.batch == 64):
+        live, live_note = live_traffic(args)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -311,12 +363,19 @@ def main():
 
         # HBM-side traffic per launch: PMC counters cannot be read from inside this process; the figures come from the
         # committed rocprofv3 --pmc passes of `bench.py --profile-region` (profiles/): default workload only
-        traffic = {}
-        if B == 64 and os.path.exists(TRAFFIC_JSON):
-            prefix = {"describe_w64": "k_describe_tiled<64,", "describe_w128": "k_describe_tiled<128,",
-                      "describe_w320": "k_describe_tiled<320,", "describe_w768": "k_describe_tiled<768,",
-                      "hessian_oct0_23": "k_hessian_nms_fused<", "hessian_oct1": "k_hessian_nms_lds<", "integral": "k_integral",
-                      "match_mfma": "k_match_bf3"}
+        traffic, traffic_source = {}, None
+        prefix = {"describe_w64": "k_describe_tiled<64,", "describe_w128": "k_describe_tiled<128,",
+                  "describe_w320": "k_describe_tiled<320,", "describe_w768": "k_describe_tiled<768,",
+                  "hessian_oct0_23": "k_hessian_nms_fused<", "hessian_oct1": "k_hessian_nms_lds<", "integral": "k_integral",
+                  "match_mfma": "k_match_bf3"}
+        if live:  # measured by this very invocation (live_traffic)
+            traffic_source = live_note
+            for st, pf in prefix.items():
+                for kname, v in live.items():
+                    if kname.startswith(pf):
+                        traffic[st] = v
+        elif B == 64 and os.path.exists(TRAFFIC_JSON):
+            traffic_source = f"committed profile {os.path.relpath(TRAFFIC_JSON, ROOT)} (live passes: {live_note})"
             tj = json.load(open(TRAFFIC_JSON))
             for st, pf in prefix.items():
                 for kname, v in tj.items():
@@ -334,7 +393,8 @@ def main():
                 else:
                     achieved, peak, unit = MFMA_EXEC_FACTOR * work / dur_s / 1e12, MFMA_BF16_PEAK_TFLOPS, "TFLOP/s"
             out = {"kernel": name, "bound": bound, "achieved": round(achieved, 3), "peak": peak, "unit": unit,
-                   "frac": round(achieved / peak, 5), "traffic": traffic.get(name), "launch_ms": round(dur_s * 1e3, 4),
+                   "frac": round(achieved / peak, 5), "traffic": traffic.get(name), "traffic_source": traffic_source if name in traffic else None,
+                   "launch_ms": round(dur_s * 1e3, 4),
                    "algorithmic_per_launch": work}
             if name in cls_samples:
                 # What bounds these kernels is VALU issue: a window sample is 24 instructions = 86 issue cycles per wavefront
