@@ -127,6 +127,9 @@ def live_traffic(args):
     import subprocess
     import tempfile
 
+    # already under a profiler (rocprofv3 -- python3 bench.py ...): no profiler inside a profiler
+    if any(k.startswith(("ROCPROF", "ROCP_", "ROCPROFILER")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this process is itself being profiled"
     exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
     if exe is None:
         return None, "rocprofv3 not found"
@@ -139,7 +142,7 @@ def live_traffic(args):
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--profile-region", "--steps", "2", "--batch", str(args.batch), "--scenes", str(args.scenes), "--matcher", args.matcher]
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=150)
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
             except subprocess.TimeoutExpired:
                 return None, f"rocprofv3 --pmc {ctr} pass timed out"
             if r.returncode != 0:
