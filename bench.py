@@ -141,12 +141,22 @@ def live_traffic(args):
             d = os.path.join(out, ctr)
             cmd = [exe, "--pmc", ctr, "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
                    "--profile-region", "--steps", "2", "--batch", str(args.batch), "--scenes", str(args.scenes), "--matcher", args.matcher]
+            # own process group: on a timeout the profiler AND the program it started are killed, nothing is left on the GPU
+            # beside the timed loop
+            pr = subprocess.Popen(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, start_new_session=True)
             try:
-                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90)
+                rc = pr.wait(timeout=90)
             except subprocess.TimeoutExpired:
+                import signal
+
+                try:
+                    os.killpg(pr.pid, signal.SIGKILL)
+                except ProcessLookupError:
+                    pass
+                pr.wait()
                 return None, f"rocprofv3 --pmc {ctr} pass timed out"
-            if r.returncode != 0:
-                return None, f"rocprofv3 --pmc {ctr} pass exited with {r.returncode}"
+            if rc != 0:
+                return None, f"rocprofv3 --pmc {ctr} pass exited with {rc}"
             vals = {}
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for row in csv.DictReader(open(f)):
