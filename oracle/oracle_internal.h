@@ -26,6 +26,7 @@ static inline uint8_t saturate_u8(int v) { return (uint8_t)(v < 0 ? 0 : (v > 255
 void integral_u8(const uint8_t* img, int rows, int cols, size_t step, int32_t* sum);
 void layer_geometry(int rows, int cols, int octave, int layer, int* size, int* step, int* lrows, int* lcols);
 void calc_layer_det_trace(const int32_t* sum, int rows, int cols, int size, int sampleStep, float* det, float* trace);
+extern float g_forced_dir;  // test hook, oracle_surf.cpp
 void fast_hessian(const int32_t* sum, int rows, int cols, float hessianThreshold, std::vector<vo_keypoint>& kps, int nOctaves = 4);
 void gaussian_kernel_f32(int n, double sigma, float* cf);
 float fastAtan2(float y, float x);

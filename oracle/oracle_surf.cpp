@@ -390,6 +390,10 @@ struct InvokerTables {
 };
 
 // One keypoint of SURFInvoker::operator().  Returns false if the keypoint is deleted.
+// test hook (vo_oracle_debug_force_angle): when >= 0 the rotated-window path uses this direction instead of the one it found, so
+// that the axis-aligned `upright` branch below can be checked against the rotated branch at 270 degrees
+float g_forced_dir = -1.f;
+
 // upright (SURF's `upright` flag, false in the reference, camera_utility.hpp:38): no orientation search - the angle is 270 and the
 // window is an axis-aligned pixel rectangle.  That branch is NOT part of SURVEY Appendix A; it restates the published OpenCV source
 // (xfeatures2d surf.cpp, SURFInvoker) and nothing in the reference exercises it: parity unpinned like the rest, one step further.
@@ -442,6 +446,7 @@ static bool describe_one(const InvokerTables& T, const uint8_t* img, size_t imgs
             }
         }
         descriptor_dir = fastAtan2(-besty, bestx);
+        if (g_forced_dir >= 0.f) descriptor_dir = g_forced_dir;
     }
     kp.angle = descriptor_dir;
     if (!vec) return true;

@@ -83,6 +83,12 @@ int vo_oracle_detect_describe(const vo_params* p, const uint8_t* img, int rows, 
     return VO_OK;
 }
 
+// test hook: degrees >= 0 make every rotated descriptor window use that direction; < 0 restores the orientation search
+int vo_oracle_debug_force_angle(float degrees) {
+    vo_oracle::g_forced_dir = degrees;
+    return VO_OK;
+}
+
 int vo_oracle_match_knn2(const float* descA, int nA, const float* descB, int nB, int32_t* idx2, float* dist2) {
     if (!descA || !descB || !idx2 || !dist2 || nA < 0 || nB < 0) return VO_ERR_INVALID_ARG;
     match_knn2(descA, nA, descB, nB, idx2, dist2);

@@ -26,6 +26,7 @@ int vo_oracle_set_threads(int n); /* OpenMP threads used by the oracle (0 = all)
 int vo_oracle_integral(const uint8_t* img, int rows, int cols, size_t step, int32_t* sum);
 int vo_oracle_hessian_layer(const uint8_t* img, int rows, int cols, size_t step, int octave, int layer,
                             float* det, float* trace);
+int vo_oracle_debug_force_angle(float degrees); /* test hook: see oracle_surf.cpp, g_forced_dir */
 int vo_oracle_detect_describe(const vo_params* p, const uint8_t* img, int rows, int cols, size_t step,
                               vo_keypoint* kps, float* desc64, int cap, int* n);
 int vo_oracle_match_knn2(const float* descA, int nA, const float* descB, int nB, int32_t* idx2, float* dist2);
