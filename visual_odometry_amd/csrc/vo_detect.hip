@@ -928,30 +928,23 @@ __device__ __forceinline__ void hessian_nms_lds_tile(unsigned char* smem, int b,
     const int prow0 = (i0 - kMarginMax) * step, pcol0 = (j0 - kMarginMax) * step;
 
     {
-        // patch rows go round the four wavefronts, 64 consecutive columns per load; RU rows (RU * KC loads) in flight
-        constexpr int RU = 4, KC = (PE + 63) / 64;
-        const int wv = tid >> 6, ln = tid & 63, nwv = NT >> 6;
-        for (int pr0 = wv; pr0 < PE; pr0 += nwv * RU) {
-            int32_t v[RU][KC];
+        // The loads write LDS directly (global_load_lds_dword: no VGPR destination, no ds_write pass), so a wavefront has ALL its
+        // rows in flight at once instead of four at a time (octave-0 launch 5.17 -> 4.80 ms).  The destination of such a load is
+        // wave-uniform base + 4 * lane: octave 0's patch is row-major (64 consecutive columns -> 64 consecutive words); octave 1
+        // stores a row's columns by parity, so a load takes every other column (lane k reads column 2k + phase).  Words outside
+        // the frame stay as they are: no kept sample reads them.
+        static_assert(HALF == 0 || HALF <= 64, "one load per (row, column phase)");
+        constexpr int KC = O == 0 ? (PE + 63) / 64 : step;
+        const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), ln = tid & 63, nwv = NT >> 6;
+        for (int pr = wv; pr < PE; pr += nwv) {
+            const int gr = prow0 + pr;
+            if (gr < 0 || gr > H) continue;  // (uniform over the wavefront)
 #pragma unroll
-            for (int u = 0; u < RU; u++) {
-                const int pr = pr0 + nwv * u, gr = prow0 + pr;
-                const bool rowok = pr < PE && gr >= 0 && gr <= H;
-#pragma unroll
-                for (int k = 0; k < KC; k++) {
-                    const int pc = ln + 64 * k, gc = pcol0 + pc;
-                    v[u][k] = 0;
-                    if (rowok && pc < PE && gc >= 0 && gc <= W) v[u][k] = sum[(size_t)gr * sw + gc];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < RU; u++) {
-                const int pr = pr0 + nwv * u;
-#pragma unroll
-                for (int k = 0; k < KC; k++) {
-                    const int pc = ln + 64 * k;
-                    if (pr < PE && pc < PE) s_sum[pr * PP + (pc & (step - 1)) * HALF + (pc >> O)] = v[u][k];
-                }
+            for (int k = 0; k < KC; k++) {
+                const int pc = O == 0 ? ln + 64 * k : ln * step + k, gc = pcol0 + pc;
+                const int dst = O == 0 ? pr * PP + 64 * k : pr * PP + k * HALF;
+                if (pc < PE && gc >= 0 && gc <= W)
+                    __builtin_amdgcn_global_load_lds(sum + (size_t)gr * sw + gc, (__attribute__((address_space(3))) void*)(s_sum + dst), 4, 0, 0);
             }
         }
     }
