@@ -1421,9 +1421,13 @@ __device__ __forceinline__ void describe_patch_to_vec(int tid, int NT, const uin
     const int lane = tid & 63;
     float* s_DX = s_grad;
     float* s_DY = s_grad + kPatch * kPatch;
+    // (the Gaussian weight is indexed per lane, i.e. it comes through a global load: the next iteration's is requested before
+    // this iteration's arithmetic, so that its latency is not waited for seven times per keypoint in the one-wavefront kernels)
+    float dw_next = c_tab.DW[min(tid, kPatch * kPatch - 1)];
     for (int it = tid; it < kPatch * kPatch; it += NT) {
         const int i = it / kPatch, j = it - i * kPatch;
-        const float dw = c_tab.DW[it];
+        const float dw = dw_next;
+        dw_next = c_tab.DW[min(it + NT, kPatch * kPatch - 1)];
         const int p00 = s_patch[i * (kPatch + 1) + j], p01 = s_patch[i * (kPatch + 1) + j + 1];
         const int p10 = s_patch[(i + 1) * (kPatch + 1) + j], p11 = s_patch[(i + 1) * (kPatch + 1) + j + 1];
         s_DX[it] = (float)(p01 - p00 + p11 - p10) * dw;
