@@ -774,3 +774,32 @@ def test_pair_batch_from_python_matches_the_batch_api(ctx):
     assert ctx.lib.vo_pair_batch(dup, 2, ins, 7, outs) == -1  # one context cannot serve two threads
     for e in extra:
         e.close()
+
+
+def test_batch_with_surf_variants_equals_the_single_calls_and_the_oracle():
+    """vo_params.n_octaves = 3 and upright through the batch path (the octave-1 launch stays, octave 3's tiles are gone, every
+    keypoint is described by the sequential kernel): records and matches equal the synchronous calls and the oracle."""
+    from visual_odometry_amd.frontend import Context, default_params
+
+    p = default_params()
+    p.n_octaves, p.upright = 3, 1
+    c = Context(p)
+    try:
+        scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 21), (400, 22), (900, 23)]]
+        b = Batch(c, len(scenes), 480, 640)
+        for i, sc in enumerate(scenes):
+            b.set_pair(i, sc.img1, sc.img2, sc.K)
+        b.run()
+        b.sync()
+        for i, sc in enumerate(scenes):
+            out = b.get(i)
+            p1, p2, m, mask, X = b.get_points(i)
+            single = c.opt_DetectFeatures(sc.img1, sc.img2)
+            assert np.array_equal(p1, single.Kpoints1) and np.array_equal(p2, single.Kpoints2)
+            rp1, rp2, rm = O.detect_match(sc.img1, sc.img2, params=p)
+            assert out.n_match == len(rm) and len(rm) > 20
+            assert np.array_equal(p1, rp1) and np.array_equal(p2, rp2)
+            assert np.array_equal(m["distance"].view(np.uint32), rm["distance"].view(np.uint32))
+        b.close()
+    finally:
+        c.close()
