@@ -2070,22 +2070,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
         lds_u8* wbase = (lds_u8*)s_win + wave * (WR * kPitch);
         int* s_rowi = reinterpret_cast<int*>(s_rowv);
         const int myrow = lane / (kPatch + 1), mycell = lane - myrow * (kPatch + 1);  // row pass: lane = (row mod 3, cell)
-        CellTab myct = {};
-        if (!area_fast) myct = s_cell[mycell];
-        // row pass (see there): the cell's byte stream starts at pixel sx1 - 1 = stream byte 0 (the head); bytes 1 .. n are the
-        // full-weight pixels.  Weights of stream bytes 0 .. 3 per lane; +0 where the byte is not part of the cell (x + 0 == x:
-        // every partial sum is >= +0)
-        // (windows above 128 px: every cell has at least five full-weight pixels, bytes 1 .. 3 always weigh a_mid)
+        // (the row pass re-reads its cell's table entry from LDS in every strip and derives its weights there: nothing of it is
+        // alive across the sampling loop, which has no registers to spare)
         constexpr bool kRpSmall = WHI <= kSmallWin;
-        const int rp_s0 = myct.sx1 - 1, rp_sx2 = myct.sx2;
-        const float rp_am = myct.a_mid;
-        const float rp_w0 = myct.has_head ? myct.a_head : 0.f, rp_wt = myct.has_tail ? myct.a_tail : 0.f;
-        float rp_w1 = rp_am, rp_w2 = rp_am, rp_w3 = rp_am;
-        if (kRpSmall) {
-            const int n = rp_sx2 - rp_s0 - 1;
-            rp_w1 = n >= 1 ? rp_am : 0.f, rp_w2 = n >= 2 ? rp_am : 0.f, rp_w3 = n >= 3 ? rp_am : 0.f;
-        }
-        const int rp_nmin = __builtin_amdgcn_readfirstlane(myct.pad) & 0xffff, rp_nmax = __builtin_amdgcn_readfirstlane(myct.pad) >> 16;
         // vertical pass state of lanes 0..20 of the first wavefront (destination column = lane; integer scales)
         int viacc = 0, dy = 0, left = iscale;
         // Vertical pass of the general case: lane (g, column) of the first wavefront, g = 0..2, folds destination rows g, g + 3,
@@ -2164,7 +2151,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                         s_rowi[(sidx * RS + wave * WR + rr) * (kPatch + 1) + cell] = tot;
                     }
                 } else if (lane < 3 * (kPatch + 1)) {
-                    // lane = (row mod 3, cell): the cell's table entry stays in registers for the whole keypoint.  The pixels a
+                    const CellTab myct = s_cell[mycell];
+                    // the cell's byte stream starts at pixel sx1 - 1 = stream byte 0 (the head); bytes 1 .. n are the full-weight
+                    // pixels.  Weights of stream bytes 0 .. 3 per lane; +0 where the byte is not part of the cell (x + 0 == x: every
+                    // partial sum is >= +0)
+                    // (windows above 128 px: every cell has at least five full-weight pixels, bytes 1 .. 3 always weigh a_mid)
+                    const int rp_s0 = myct.sx1 - 1, rp_sx2 = myct.sx2;
+                    const float rp_am = myct.a_mid;
+                    const float rp_w0 = myct.has_head ? myct.a_head : 0.f, rp_wt = myct.has_tail ? myct.a_tail : 0.f;
+                    float rp_w1 = rp_am, rp_w2 = rp_am, rp_w3 = rp_am;
+                    if (kRpSmall) {
+                        const int n = rp_sx2 - rp_s0 - 1;
+                        rp_w1 = n >= 1 ? rp_am : 0.f, rp_w2 = n >= 2 ? rp_am : 0.f, rp_w3 = n >= 3 ? rp_am : 0.f;
+                    }
+                    const int rp_nmin = __builtin_amdgcn_readfirstlane(myct.pad) & 0xffff, rp_nmax = __builtin_amdgcn_readfirstlane(myct.pad) >> 16;
+                    // lane = (row mod 3, cell).  The pixels a
                     // cell reads are contiguous - head (sx1 - 1), full-weight pixels [sx1, sx2), tail (sx2) - so they come in
                     // as a byte stream of ALIGNED words shifted into place (v_alignbyte): one LDS read per four pixels.  The
                     // adds stay in pixel order; a pixel past a lane's own count is added with weight 0 or not at all.
