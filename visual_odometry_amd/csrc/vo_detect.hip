@@ -1856,21 +1856,19 @@ __device__ __forceinline__ int bilinear_u8(uint32_t q, float a, float b) {
     return (int)__builtin_amdgcn_cvt_pk_u8_f32(v, 0u, 0u);
 }
 
-// U samples of one lane at columns j0 + u * CB, all inside the window.  (px0, py0) is the exact position of
-// column j0, (dxs, dys) the exact step of CB columns.  Coordinates are linear in the column, so the batch lies
-// in the frame interior iff its first and last sample do; then the 2 * U tap loads go out back to back.
-template <int U, int CB, bool CHECK>
+// U samples of one lane at columns j0 + u * CB, all inside the window, walked in double precision.  (px0, py0) is the exact
+// position of column j0, (dxs, dys) the exact step of CB columns.  Coordinates are linear in the column, so the batch lies
+// in the frame interior iff its first and last sample do; then the U footprint loads go out back to back.  (The rows of
+// windows inside the frame whose coordinates are multiples of 2^-32 - nearly all - take sample_batch_fix instead.)
+template <int U, int CB>
 __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, const uint32_t* __restrict__ quad, int W, int qs8,
                                              int ncols1, int nrows1, double px0, double py0, double dxs, double dys,
                                              lds_u8* wdst) {
-    bool ok = true;
-    if (CHECK) {  // !CHECK: the caller has verified the whole strip of rows
-        const double pxl = px0 + (double)(U - 1) * dxs, pyl = py0 + (double)(U - 1) * dys;
-        const int ix0 = (int)floor(px0), iy0 = (int)floor(py0), ixl = (int)floor(pxl), iyl = (int)floor(pyl);
-        ok = (unsigned)ix0 < (unsigned)ncols1 && (unsigned)iy0 < (unsigned)nrows1 && (unsigned)ixl < (unsigned)ncols1 &&
-             (unsigned)iyl < (unsigned)nrows1;
-    }
-    if (!CHECK || __ballot(!ok) == 0ull) {
+    const double pxl = px0 + (double)(U - 1) * dxs, pyl = py0 + (double)(U - 1) * dys;
+    const int ix0 = (int)floor(px0), iy0 = (int)floor(py0), ixl = (int)floor(pxl), iyl = (int)floor(pyl);
+    const bool ok = (unsigned)ix0 < (unsigned)ncols1 && (unsigned)iy0 < (unsigned)nrows1 && (unsigned)ixl < (unsigned)ncols1 &&
+                    (unsigned)iyl < (unsigned)nrows1;
+    if (__ballot(!ok) == 0ull) {
         float a[U], b[U];
         uint32_t q[U];
         double px = px0, py = py0;
@@ -1902,6 +1900,63 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
             py += dys;
         }
     }
+}
+
+// ---- 32.32 fixed-point walk of the interior samples ----------------------------------------------------------------------
+// When cos, sin and a row's start are 0 or >= 2^-9 in magnitude (floats: multiples of 2^-32) every coordinate start + j * step of
+// the row is a multiple of 2^-32 below 2^13, i.e. an exact 32.32 fixed-point number: one 64-bit add steps it, the high word is
+// floor(p), and v_cvt_f32_u32 of the low word is 2^32 times the reference's (float)(p - floor(p)) - the same rounding, scaled
+// by a power of two.  The bilinear weights carry that factor (2^32 - A is 2^32 * fl(1 - a), products and sums scale exactly:
+// nothing under- or overflows between 255 * 2^-48 * 2^64 and 255 * 2^64) and the sum is multiplied by 2^-64 before the u8
+// rounding.  21 instead of 24 instructions per sample and no double-precision arithmetic in the loop.
+__device__ __forceinline__ bool exact32(float v) { return v == 0.f || fabsf(v) >= 0x1p-9f; }
+__device__ __forceinline__ uint64_t to_fix32(double p) {  // p >= 0, a multiple of 2^-32 below 2^32
+    const uint32_t hi = (uint32_t)(int)p;
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fract(p) * 4294967296.0);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t add_u64(uint64_t a, uint64_t b_uniform) {
+    uint64_t r;
+    asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
+    return r;
+}
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ int bilinear_u8_fix(uint32_t q, float A, float B) {  // A = 2^32 a, B = 2^32 b
+    const f32x2 wx = {4294967296.f - A, A};
+    const float omb = 4294967296.f - B;
+    f32x2 r0 = {(float)(q & 255u), (float)((q >> 8) & 255u)};
+    f32x2 r1 = {(float)((q >> 16) & 255u), (float)(q >> 24)};
+    r0 = r0 * wx;
+    r1 = r1 * wx;
+    r0 = r0 * omb;
+    r1 = r1 * B;
+    float v = r0.x + r0.y;
+    v = v + r1.x;
+    v = v + r1.y;
+    return (int)__builtin_amdgcn_cvt_pk_u8_f32(v * 0x1p-64f, 0u, 0u);
+}
+template <int U, int CB>
+__device__ __forceinline__ void sample_batch_fix(const uint32_t* __restrict__ quad, int qs8, uint64_t& X, uint64_t& Y, uint64_t DX,
+                                                 uint64_t DY, lds_u8* wdst) {
+    float A[U], B[U];
+    uint32_t q[U];
+#pragma unroll
+    for (int u = 0; u < U; u++) {
+        A[u] = (float)(uint32_t)X;
+        B[u] = (float)(uint32_t)Y;
+        const uint32_t xi = (uint32_t)(X >> 32), yi = (uint32_t)(Y >> 32);
+        uint32_t boff = (uint32_t)__mul24((int)(xi >> 3), qs8);
+        asm("v_lshl_add_u32 %0, %1, 5, %0" : "+v"(boff) : "v"(yi));
+        asm("v_lshl_add_u32 %0, %1, 2, %0" : "+v"(boff) : "v"(xi));
+        q[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const unsigned char*>(quad) + boff);
+        X = add_u64(X, DX);
+        Y = add_u64(Y, DY);
+    }
+#pragma unroll
+    for (int u = 0; u < U; u++) wdst[u * CB] = (uint8_t)bilinear_u8_fix(q[u], A[u], B[u]);
 }
 
 // The decimation tables depend on the window size only: built once per context for every size the tiled kernels see
@@ -2053,6 +2108,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
         const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
         const double dxs = (double)CB * dcos, dys = (double)CB * ndsin;  // exact: CB is a power of two
         bool bad = force_seq != 0 || !(exact_step(cos_dir) && exact_step(sin_dir));
+        const bool fix_ok = exact32(cos_dir) && exact32(sin_dir);
+        const uint64_t fdx = uniform_u64((uint64_t)(long long)(dxs * 4294967296.0)), fdy = uniform_u64((uint64_t)(long long)(dys * 4294967296.0));
         if (tid >= NT - 2) {
             // row starts are a sequential FLOAT accumulation (start_x += sin_dir): two lanes walk it once per keypoint
             const bool isy = tid == NT - 1;
@@ -2105,13 +2162,39 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                     row_in = (unsigned)(int)floor(sxd) < (unsigned)ncols1 && (unsigned)(int)floor(syd) < (unsigned)nrows1 &&
                              (unsigned)(int)floor(pxe) < (unsigned)ncols1 && (unsigned)(int)floor(pye) < (unsigned)nrows1;
                 }
-                auto sample_rows = [&](auto chk) {
-                    constexpr bool CK = decltype(chk)::value;
+                auto sample_rows_fix = [&]() {
+                    uint64_t X = to_fix32(__builtin_fma((double)c, dcos, sxd)), Y = to_fix32(__builtin_fma((double)c, ndsin, syd));
+                    int jb = 0;
+                    if constexpr (UMAX >= 8) {
+                        for (; jb + 8 * CB <= win; jb += 8 * CB) sample_batch_fix<8, CB>(quad, qs8, X, Y, fdx, fdy, wrow + jb + c);
+                        if (jb + 4 * CB <= win) {
+                            sample_batch_fix<4, CB>(quad, qs8, X, Y, fdx, fdy, wrow + jb + c);
+                            jb += 4 * CB;
+                        }
+                    } else {
+                        for (; jb + 4 * CB <= win; jb += 4 * CB) sample_batch_fix<4, CB>(quad, qs8, X, Y, fdx, fdy, wrow + jb + c);
+                    }
+                    if (jb + 2 * CB <= win) {
+                        sample_batch_fix<2, CB>(quad, qs8, X, Y, fdx, fdy, wrow + jb + c);
+                        jb += 2 * CB;
+                    }
+                    if (jb + CB <= win) {
+                        sample_batch_fix<1, CB>(quad, qs8, X, Y, fdx, fdy, wrow + jb + c);
+                        jb += CB;
+                    }
+                    if (jb < win) {
+                        const int jc = min(jb + c, win - 1);
+                        const double jd = (double)jc;
+                        uint64_t Xl = to_fix32(__builtin_fma(jd, dcos, sxd)), Yl = to_fix32(__builtin_fma(jd, ndsin, syd));
+                        sample_batch_fix<1, CB>(quad, qs8, Xl, Yl, fdx, fdy, wrow + jc);
+                    }
+                };
+                auto sample_rows = [&]() {
                     int jb = 0;
 #define VO_BATCH(UU)                                                                                                          \
     {                                                                                                                         \
         const double jd = (double)(jb + c);                                                                                   \
-        sample_batch<UU, CB, CK>(img, quad, W, qs8, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs, \
+        sample_batch<UU, CB>(img, quad, W, qs8, ncols1, nrows1, __builtin_fma(jd, dcos, sxd), __builtin_fma(jd, ndsin, syd), dxs,     \
                                  dys, wrow + jb + c);                                                                         \
         jb += UU * CB;                                                                                                        \
     }
@@ -2127,17 +2210,17 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                     if (jb < win) {  // last, partial group of columns: lanes past the window repeat its last column
                         const int jc = min(jb + c, win - 1);
                         const double jd = (double)jc;
-                        sample_batch<1, CB, CK>(img, quad, W, qs8, ncols1, nrows1, __builtin_fma(jd, dcos, sxd),
-                                                __builtin_fma(jd, ndsin, syd), dxs, dys, wrow + jc);
+                        sample_batch<1, CB>(img, quad, W, qs8, ncols1, nrows1, __builtin_fma(jd, dcos, sxd),
+                                            __builtin_fma(jd, ndsin, syd), dxs, dys, wrow + jc);
                     }
                 };
                 // interior AND every coordinate a multiple of 2^-32: the fixed-point walk; anything else (a window across the frame
                 // border; |cos|, |sin| or a row start below 2^-9, 0.3 % of the keypoints) takes the double-precision walk with its
-                // per-batch interior test
-                if (__ballot(!row_in) == 0ull)
-                    sample_rows(std::false_type{});
+                // per-batch interior test (wave-uniform choice)
+                if (__ballot(!(row_in && fix_ok && exact32(start_x) && exact32(start_y))) == 0ull)
+                    sample_rows_fix();
                 else
-                    sample_rows(std::true_type{});
+                    sample_rows();
               }
                 wave_sync_lds();
                 // INTER_AREA row pass: one (row, destination cell) per lane, the cell's pixels in table order
