@@ -1915,14 +1915,12 @@ __device__ __forceinline__ uint64_t to_fix32(double p) {  // p >= 0, a multiple 
     const uint32_t lo = (uint32_t)(__builtin_amdgcn_fract(p) * 4294967296.0);
     return ((uint64_t)hi << 32) | lo;
 }
+// one instruction; the step is wave-uniform and stays in an SGPR pair (a VGPR pair would make the add full rate, but the 96-register
+// classes have no registers to spare: measured 17.80 -> 17.60 ms over the four classes with the step in SGPRs)
 __device__ __forceinline__ uint64_t add_u64(uint64_t a, uint64_t b_uniform) {
     uint64_t r;
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
     return r;
-}
-__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
-    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
-    return ((uint64_t)hi << 32) | lo;
 }
 __device__ __forceinline__ int bilinear_u8_fix(uint32_t q, float A, float B) {  // A = 2^32 a, B = 2^32 b
     const f32x2 wx = {4294967296.f - A, A};
@@ -1938,6 +1936,18 @@ __device__ __forceinline__ int bilinear_u8_fix(uint32_t q, float A, float B) {  
     v = v + r1.y;
     return (int)__builtin_amdgcn_cvt_pk_u8_f32(v * 0x1p-64f, 0u, 0u);
 }
+// (the compiler drops a readfirstlane of a value it knows to be uniform and then keeps that value in VGPRs, also as the "s"
+// operand of inline assembly; the empty asm hides where the value comes from.  The readfirstlane itself stays a builtin: an
+// SGPR written by a VALU instruction needs two wait states before a VALU instruction reads it on this part, and the
+// compiler's hazard pass does not look inside inline assembly)
+__device__ __forceinline__ uint64_t uniform_u64(uint64_t v) {
+    uint32_t lo = (uint32_t)v, hi = (uint32_t)(v >> 32);
+    asm volatile("" : "+v"(lo), "+v"(hi));
+    lo = __builtin_amdgcn_readfirstlane(lo);
+    hi = __builtin_amdgcn_readfirstlane(hi);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ double uniform_f64(double v) { return __builtin_bit_cast(double, uniform_u64(__builtin_bit_cast(uint64_t, v))); }
 template <int U, int CB>
 __device__ __forceinline__ void sample_batch_fix(const uint32_t* __restrict__ quad, int qs8, uint64_t& X, uint64_t& Y, uint64_t DX,
                                                  uint64_t DY, lds_u8* wdst) {
@@ -2105,10 +2115,13 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
         if (tid == 0) n_code = *(volatile const int*)&list[min(n_item, n_items - 1)];  // look-ahead stage 2: list entry
         const float win_offset = -(float)(win - 1) / 2;
         const int ncols1 = W - 1, nrows1 = H - 1, qs8 = 32 * H - 32;  // see sample_batch
-        const double dcos = (double)cos_dir, ndsin = -(double)sin_dir;
+        // wave-uniform values that live across the sampling loop are pinned to SGPRs (uniform_*): left to itself the compiler
+        // keeps them in VGPRs, and the 96-register classes spill for every pair of them
+        const double dcos = uniform_f64((double)cos_dir), ndsin = uniform_f64(-(double)sin_dir);
         const double dxs = (double)CB * dcos, dys = (double)CB * ndsin;  // exact: CB is a power of two
         bool bad = force_seq != 0 || !(exact_step(cos_dir) && exact_step(sin_dir));
         const bool fix_ok = exact32(cos_dir) && exact32(sin_dir);
+        // the step of CB columns in 32.32 (two's complement: a negative step wraps, which is what the 64-bit add needs)
         const uint64_t fdx = uniform_u64((uint64_t)(long long)(dxs * 4294967296.0)), fdy = uniform_u64((uint64_t)(long long)(dys * 4294967296.0));
         if (tid >= NT - 2) {
             // row starts are a sequential FLOAT accumulation (start_x += sin_dir): two lanes walk it once per keypoint
