@@ -1910,9 +1910,9 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
 // nothing under- or overflows between 255 * 2^-48 * 2^64 and 255 * 2^64) and the sum is multiplied by 2^-64 before the u8
 // rounding.  21 instead of 24 instructions per sample and no double-precision arithmetic in the loop.
 __device__ __forceinline__ bool exact32(float v) { return v == 0.f || fabsf(v) >= 0x1p-9f; }
-__device__ __forceinline__ uint64_t to_fix32(double p) {  // p >= 0, a multiple of 2^-32 below 2^32
-    const uint32_t hi = (uint32_t)(int)p;
-    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fract(p) * 4294967296.0);
+__device__ __forceinline__ uint64_t fix32_from_float(float v) {  // v >= 0, a multiple of 2^-32 below 2^32 (v == 0 or v >= 2^-9)
+    const uint32_t hi = (uint32_t)v;  // v >= 0: truncation is floor
+    const uint32_t lo = (uint32_t)(__builtin_amdgcn_fractf(v) * 4294967296.f);  // v - floor(v) and the scaling are exact
     return ((uint64_t)hi << 32) | lo;
 }
 // one instruction; the step is wave-uniform and stays in an SGPR pair (a VGPR pair would make the add full rate, but the 96-register
@@ -2122,7 +2122,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
         bool bad = force_seq != 0 || !(exact_step(cos_dir) && exact_step(sin_dir));
         const bool fix_ok = exact32(cos_dir) && exact32(sin_dir);
         // the step of CB columns in 32.32 (two's complement: a negative step wraps, which is what the 64-bit add needs)
-        const uint64_t fdx = uniform_u64((uint64_t)(long long)(dxs * 4294967296.0)), fdy = uniform_u64((uint64_t)(long long)(dys * 4294967296.0));
+        const long long fcos = (long long)(dcos * 4294967296.0), fnsin = (long long)(ndsin * 4294967296.0);  // step of one column
+        const uint64_t fdx = uniform_u64((uint64_t)(fcos * CB)), fdy = uniform_u64((uint64_t)(fnsin * CB));
+        const uint64_t fendx = uniform_u64((uint64_t)(fcos * (win - 1))), fendy = uniform_u64((uint64_t)(fnsin * (win - 1)));  // column 0 -> last column
+        const uint64_t fcx = (uint64_t)(fcos * c), fcy = (uint64_t)(fnsin * c);                                           // column 0 -> this lane's
         if (tid >= NT - 2) {
             // row starts are a sequential FLOAT accumulation (start_x += sin_dir): two lanes walk it once per keypoint
             const bool isy = tid == NT - 1;
@@ -2136,6 +2139,21 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
             }
         }
         __syncthreads();
+
+        // Is the WHOLE window in the frame interior, with every coordinate exact in 32.32?  Row starts are float accumulations of
+        // a constant, hence monotone in the row index: every row's start lies between the first and the last row's, and so does
+        // its end (start + (win - 1) * step, exact in double).  The four corners decide for all rows, and the per-group tests
+        // below (interior, exactness of the row start: ~45 instructions per group of RB rows, a third of the sampling itself for
+        // a 45-pixel window) run only for windows that touch the frame border.
+        bool fix_all;
+        {
+            const float sx0 = s_sx[0], sxn = s_sx[win - 1], sy0 = s_sy[0], syn = s_sy[win - 1];
+            const float xlo = fminf(sx0, sxn), xhi = fmaxf(sx0, sxn), ylo = fminf(sy0, syn), yhi = fmaxf(sy0, syn);
+            const double ex = (double)(win - 1) * dcos, ey = (double)(win - 1) * ndsin;  // exact
+            fix_all = fix_ok && xlo >= 0x1p-9f && ylo >= 0x1p-9f && xhi < 7000.f && yhi < 7000.f && (double)xhi < (double)ncols1 &&
+                      (double)yhi < (double)nrows1 && (double)xlo + ex >= 0.0 && (double)xhi + ex < (double)ncols1 &&
+                      (double)ylo + ey >= 0.0 && (double)yhi + ey < (double)nrows1;
+        }
 
         lds_u8* wbase = (lds_u8*)s_win + wave * (WR * kPitch);
         int* s_rowi = reinterpret_cast<int*>(s_rowv);
@@ -2163,20 +2181,23 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                 // that every lane computes a valid sample and no load needs a guard
                 const int irow = grow0 + r < win ? grow0 + r : grow0;
                 const float start_x = s_sx[irow], start_y = s_sy[irow];
-                bad = bad || !(exact_start(start_x) && exact_start(start_y));
-                const double sxd = (double)start_x, syd = (double)start_y;
                 lds_u8* wrow = wbase + (g * RB + r) * kPitch;
-                // rows whose two ends lie in the frame interior are interior throughout (the walk is a straight line):
-                // one test per group instead of one per batch
-                bool row_in;
-                {
-                    const double jl = (double)(win - 1);
+                // interior AND every coordinate a multiple of 2^-32: the fixed-point walk; anything else (a row across the frame
+                // border; |cos|, |sin| or a row start below 2^-9, 0.3 % of the keypoints) takes the double-precision walk with its
+                // per-batch interior test (wave-uniform choice)
+                bool use_fix = fix_all;
+                if (!fix_all) {
+                    bad = bad || !(exact_start(start_x) && exact_start(start_y));
+                    // a row whose two ends lie in the frame interior is interior throughout (the walk is a straight line)
+                    const double sxd = (double)start_x, syd = (double)start_y, jl = (double)(win - 1);
                     const double pxe = __builtin_fma(jl, dcos, sxd), pye = __builtin_fma(jl, ndsin, syd);
-                    row_in = (unsigned)(int)floor(sxd) < (unsigned)ncols1 && (unsigned)(int)floor(syd) < (unsigned)nrows1 &&
-                             (unsigned)(int)floor(pxe) < (unsigned)ncols1 && (unsigned)(int)floor(pye) < (unsigned)nrows1;
+                    const bool row_in = (unsigned)(int)floor(sxd) < (unsigned)ncols1 && (unsigned)(int)floor(syd) < (unsigned)nrows1 &&
+                                        (unsigned)(int)floor(pxe) < (unsigned)ncols1 && (unsigned)(int)floor(pye) < (unsigned)nrows1;
+                    use_fix = __ballot(!(row_in && fix_ok && exact32(start_x) && exact32(start_y))) == 0ull;
                 }
                 auto sample_rows_fix = [&]() {
-                    uint64_t X = to_fix32(__builtin_fma((double)c, dcos, sxd)), Y = to_fix32(__builtin_fma((double)c, ndsin, syd));
+                    const uint64_t X0 = fix32_from_float(start_x), Y0 = fix32_from_float(start_y);  // column 0 of this lane's row
+                    uint64_t X = X0 + fcx, Y = Y0 + fcy;
                     int jb = 0;
                     if constexpr (UMAX >= 8) {
                         for (; jb + 8 * CB <= win; jb += 8 * CB) sample_batch_fix<8, CB>(quad, qs8, X, Y, fdx, fdy, wrow + jb + c);
@@ -2195,14 +2216,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                         sample_batch_fix<1, CB>(quad, qs8, X, Y, fdx, fdy, wrow + jb + c);
                         jb += CB;
                     }
-                    if (jb < win) {
-                        const int jc = min(jb + c, win - 1);
-                        const double jd = (double)jc;
-                        uint64_t Xl = to_fix32(__builtin_fma(jd, dcos, sxd)), Yl = to_fix32(__builtin_fma(jd, ndsin, syd));
-                        sample_batch_fix<1, CB>(quad, qs8, Xl, Yl, fdx, fdy, wrow + jc);
+                    if (jb < win) {  // last, partial group of columns: lanes past the window repeat its last column
+                        const bool past = jb + c > win - 1;
+                        uint64_t Xl = past ? add_u64(X0, fendx) : X, Yl = past ? add_u64(Y0, fendy) : Y;
+                        sample_batch_fix<1, CB>(quad, qs8, Xl, Yl, fdx, fdy, wrow + min(jb + c, win - 1));
                     }
                 };
                 auto sample_rows = [&]() {
+                    const double sxd = (double)start_x, syd = (double)start_y;
                     int jb = 0;
 #define VO_BATCH(UU)                                                                                                          \
     {                                                                                                                         \
@@ -2227,10 +2248,7 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                                             __builtin_fma(jd, ndsin, syd), dxs, dys, wrow + jc);
                     }
                 };
-                // interior AND every coordinate a multiple of 2^-32: the fixed-point walk; anything else (a window across the frame
-                // border; |cos|, |sin| or a row start below 2^-9, 0.3 % of the keypoints) takes the double-precision walk with its
-                // per-batch interior test (wave-uniform choice)
-                if (__ballot(!(row_in && fix_ok && exact32(start_x) && exact32(start_y))) == 0ull)
+                if (use_fix)
                     sample_rows_fix();
                 else
                     sample_rows();
