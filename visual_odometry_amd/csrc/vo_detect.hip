@@ -1906,9 +1906,8 @@ __device__ __forceinline__ void sample_batch(const uint8_t* __restrict__ img, co
 // When cos, sin and a row's start are 0 or >= 2^-9 in magnitude (floats: multiples of 2^-32) every coordinate start + j * step of
 // the row is a multiple of 2^-32 below 2^13, i.e. an exact 32.32 fixed-point number: one 64-bit add steps it, the high word is
 // floor(p), and v_cvt_f32_u32 of the low word is 2^32 times the reference's (float)(p - floor(p)) - the same rounding, scaled
-// by a power of two.  The bilinear weights carry that factor (2^32 - A is 2^32 * fl(1 - a), products and sums scale exactly:
-// nothing under- or overflows between 255 * 2^-48 * 2^64 and 255 * 2^64) and the sum is multiplied by 2^-64 before the u8
-// rounding.  21 instead of 24 instructions per sample and no double-precision arithmetic in the loop.
+// by a power of two.  The bilinear weights carry that factor (2^32 - A is 2^32 * fl(1 - a); products and sums scale exactly as long
+// as nothing under- or overflows, see bilinear_u8_fix).  No double-precision arithmetic in the loop.
 __device__ __forceinline__ bool exact32(float v) { return v == 0.f || fabsf(v) >= 0x1p-9f; }
 __device__ __forceinline__ uint64_t fix32_from_float(float v) {  // v >= 0, a multiple of 2^-32 below 2^32 (v == 0 or v >= 2^-9)
     const uint32_t hi = (uint32_t)v;  // v >= 0: truncation is floor
@@ -1922,19 +1921,33 @@ __device__ __forceinline__ uint64_t add_u64(uint64_t a, uint64_t b_uniform) {
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
     return r;
 }
-__device__ __forceinline__ int bilinear_u8_fix(uint32_t q, float A, float B) {  // A = 2^32 a, B = 2^32 b
-    const f32x2 wx = {4294967296.f - A, A};
+// byte K of q, taken as the float whose bits it is (the denormal byte * 2^-149), times w: ONE instruction where the conversion
+// and the product would be two.  The f32 denormal mode of these kernels is IEEE, so the product is the correctly rounded
+// byte * w * 2^-149 as long as it is a normal number - the caller's scaling sees to that.
+template <int K>
+__device__ __forceinline__ float mul_byte_denorm(uint32_t q, float w) {
+    float r;
+    static_assert(K >= 0 && K < 4, "byte index");
+    if (K == 0) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_0 src1_sel:DWORD" : "=v"(r) : "v"(q), "v"(w));
+    if (K == 1) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_1 src1_sel:DWORD" : "=v"(r) : "v"(q), "v"(w));
+    if (K == 2) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_2 src1_sel:DWORD" : "=v"(r) : "v"(q), "v"(w));
+    if (K == 3) asm("v_mul_f32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:BYTE_3 src1_sel:DWORD" : "=v"(r) : "v"(q), "v"(w));
+    return r;
+}
+// A = 2^32 a, B = 2^32 b.  The x weights are carried at 2^117 (= 2^32 * 2^85): a pixel byte read as a denormal is p * 2^-149, so
+// the first product is 2^-32 * fl(p * (1 - a)) (between 2^-56 and 2^-24: normal), the second, by 2^32 (1 - b) or 2^32 b, is the
+// reference's own value, and the sum needs no rescaling.
+__device__ __forceinline__ int bilinear_u8_fix(uint32_t q, float A, float B) {
+    const float w1 = A * 0x1p85f, w0 = 0x1p117f - w1;  // exact scalings of a and of fl(1 - a)
     const float omb = 4294967296.f - B;
-    f32x2 r0 = {(float)(q & 255u), (float)((q >> 8) & 255u)};
-    f32x2 r1 = {(float)((q >> 16) & 255u), (float)(q >> 24)};
-    r0 = r0 * wx;
-    r1 = r1 * wx;
+    f32x2 r0 = {mul_byte_denorm<0>(q, w0), mul_byte_denorm<1>(q, w1)};
+    f32x2 r1 = {mul_byte_denorm<2>(q, w0), mul_byte_denorm<3>(q, w1)};
     r0 = r0 * omb;
     r1 = r1 * B;
     float v = r0.x + r0.y;
     v = v + r1.x;
     v = v + r1.y;
-    return (int)__builtin_amdgcn_cvt_pk_u8_f32(v * 0x1p-64f, 0u, 0u);
+    return (int)__builtin_amdgcn_cvt_pk_u8_f32(v, 0u, 0u);
 }
 // (the compiler drops a readfirstlane of a value it knows to be uniform and then keeps that value in VGPRs, also as the "s"
 // operand of inline assembly; the empty asm hides where the value comes from.  The readfirstlane itself stays a builtin: an
