@@ -2283,9 +2283,12 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                     // pixels.  Weights of stream bytes 0 .. 3 per lane; +0 where the byte is not part of the cell (x + 0 == x: every
                     // partial sum is >= +0)
                     // (windows above 128 px: every cell has at least five full-weight pixels, bytes 1 .. 3 always weigh a_mid)
+                    // (weights carried at 2^127: a pixel byte enters its product as the denormal float whose bits it is,
+                    // mul_byte_denorm; the weights are in [2^-16, 1], so every product b * a * 2^-22 is normal and rounds as
+                    // b * a does, the sums scale with it, and the result is multiplied by 2^22 before it is stored)
                     const int rp_s0 = myct.sx1 - 1, rp_sx2 = myct.sx2;
-                    const float rp_am = myct.a_mid;
-                    const float rp_w0 = myct.has_head ? myct.a_head : 0.f, rp_wt = myct.has_tail ? myct.a_tail : 0.f;
+                    const float rp_am = myct.a_mid * 0x1p127f;
+                    const float rp_w0 = myct.has_head ? myct.a_head * 0x1p127f : 0.f, rp_wt = myct.has_tail ? myct.a_tail * 0x1p127f : 0.f;
                     float rp_w1 = rp_am, rp_w2 = rp_am, rp_w3 = rp_am;
                     if (kRpSmall) {
                         const int n = rp_sx2 - rp_s0 - 1;
@@ -2306,35 +2309,35 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                         uint32_t lo = q[0], hi = q[1];
                         const int pt = p[rp_sx2];
                         uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
-                        float acc = (float)(w & 255u) * rp_w0;  // head, or +0
-                        acc += (float)((w >> 8) & 255u) * rp_w1;
-                        acc += (float)((w >> 16) & 255u) * rp_w2;
-                        acc += (float)(w >> 24) * rp_w3;
+                        float acc = mul_byte_denorm<0>(w, rp_w0);  // head, or +0
+                        acc += mul_byte_denorm<1>(w, rp_w1);
+                        acc += mul_byte_denorm<2>(w, rp_w2);
+                        acc += mul_byte_denorm<3>(w, rp_w3);
                         int j = 4, qi = 2;
                         for (; j + 3 <= rp_nmin; j += 4, qi++) {  // stream bytes j .. j + 3 are full-weight pixels in every lane
                             lo = hi;
                             hi = q[qi];
                             w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
-                            acc += (float)(w & 255u) * rp_am;
-                            acc += (float)((w >> 8) & 255u) * rp_am;
-                            acc += (float)((w >> 16) & 255u) * rp_am;
-                            acc += (float)(w >> 24) * rp_am;
+                            acc += mul_byte_denorm<0>(w, rp_am);
+                            acc += mul_byte_denorm<1>(w, rp_am);
+                            acc += mul_byte_denorm<2>(w, rp_am);
+                            acc += mul_byte_denorm<3>(w, rp_am);
                         }
                         for (; j <= rp_nmax; j += 4, qi++) {  // lanes past their own count keep acc
                             lo = hi;
                             hi = q[qi];
                             w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
-                            const float a0 = acc + (float)(w & 255u) * rp_am;
+                            const float a0 = acc + mul_byte_denorm<0>(w, rp_am);
                             acc = j <= rp_n ? a0 : acc;
-                            const float a1 = acc + (float)((w >> 8) & 255u) * rp_am;
+                            const float a1 = acc + mul_byte_denorm<1>(w, rp_am);
                             acc = j + 1 <= rp_n ? a1 : acc;
-                            const float a2 = acc + (float)((w >> 16) & 255u) * rp_am;
+                            const float a2 = acc + mul_byte_denorm<2>(w, rp_am);
                             acc = j + 2 <= rp_n ? a2 : acc;
-                            const float a3 = acc + (float)(w >> 24) * rp_am;
+                            const float a3 = acc + mul_byte_denorm<3>(w, rp_am);
                             acc = j + 3 <= rp_n ? a3 : acc;
                         }
-                        acc += (float)pt * rp_wt;  // tail, or +0
-                        *outp = acc;
+                        acc += mul_byte_denorm<0>((uint32_t)pt, rp_wt);  // tail, or +0
+                        *outp = acc * 0x1p22f;
                     }
                 }
             }
