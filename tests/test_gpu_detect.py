@@ -139,6 +139,37 @@ def test_keypoints_at_frame_border_use_clamped_sampler(ctx):
     assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
 
 
+@pytest.mark.parametrize("seed", [5, 6, 7])
+def test_large_windows_across_the_frame_border(ctx, seed):
+    """Wide blobs all over a 600 x 800 frame, also hard against its edges: descriptor windows of 100 - 700 pixels of which many
+    leave the frame on one or two sides.  The sampler decides per keypoint (four corners) and per group of eight rows whether
+    rows are walked in 32.32 fixed point without interior tests or in double precision with one test per batch; every mix of
+    the two inside one window must give the oracle's bits."""
+    rng = np.random.default_rng(seed)
+    h, w = 600, 800
+    img = np.full((h, w), 90.0, np.float32)
+    yy, xx = np.mgrid[0:h, 0:w]
+    for _ in range(70):
+        cy, cx = rng.integers(-10, h + 10), rng.integers(-10, w + 10)
+        sg = rng.uniform(4.0, 32.0)
+        ax = rng.uniform(0.5, 1.0)  # anisotropic: orientations spread over the circle
+        th = rng.uniform(0, np.pi)
+        u = (xx - cx) * np.cos(th) + (yy - cy) * np.sin(th)
+        v = -(xx - cx) * np.sin(th) + (yy - cy) * np.cos(th)
+        img += rng.uniform(-70, 110) * np.exp(-(u * u / (2 * sg * sg) + v * v / (2 * (ax * sg) ** 2)))
+    img = np.clip(img + rng.normal(0, 2.0, size=img.shape), 0, 255).astype(np.uint8)
+    k, d = ctx.detect_describe(img)
+    rk, rd = O.detect_describe(img)
+    _assert_kps_equal(k, rk)
+    win = _window_sizes(k)
+    half = 0.75 * win  # a rotated window reaches up to win / sqrt(2) from its centre
+    crossing = (k["x"] < half) | (k["y"] < half) | (k["x"] > w - half) | (k["y"] > h - half)
+    assert (win > 128).sum() > 20 and (crossing & (win > 128)).sum() > 10, ((win > 128).sum(), crossing.sum())
+    assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+    bad = np.flatnonzero((d.view(np.uint32) != rd.view(np.uint32)).any(axis=1))
+    assert len(bad) == 0, (len(bad), len(k), bad[:10], win[bad[:10]])
+
+
 def test_uniform_image_has_no_keypoints(ctx):
     img = np.full((200, 300), 77, np.uint8)
     k, d = ctx.detect_describe(img)
