@@ -1916,6 +1916,8 @@ __device__ __forceinline__ uint64_t fix32_from_float(float v) {  // v >= 0, a mu
 }
 // one instruction; the step is wave-uniform and stays in an SGPR pair (a VGPR pair would make the add full rate, but the 96-register
 // classes have no registers to spare: measured 17.80 -> 17.60 ms over the four classes with the step in SGPRs)
+// (the SGPR pairs it reads are written by v_readfirstlane at the top of a keypoint, hundreds of instructions before the first add:
+// the two wait states a VALU read of a VALU-written SGPR needs are not the compiler's to insert around inline assembly)
 __device__ __forceinline__ uint64_t add_u64(uint64_t a, uint64_t b_uniform) {
     uint64_t r;
     asm("v_lshl_add_u64 %0, %1, 0, %2" : "=v"(r) : "v"(a), "s"(b_uniform));
