@@ -142,6 +142,25 @@ def test_matcher_device_code_has_no_mfma_read_hazard():
     assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_mfma_hazard.py")]) == 0
 
 
+def test_detection_device_code_has_no_sgpr_hazard_at_inline_assembly():
+    """An SGPR written by a VALU instruction needs two wait states before a VALU instruction reads it on gfx950, and the compiler
+    does not look inside inline assembly: tools/check_sgpr_hazard.py scans the compiled vo_detect.hip for it (and the scanner
+    itself is checked on a hand-written violation first)."""
+    import importlib.util, subprocess
+
+    spec = importlib.util.spec_from_file_location("check_sgpr_hazard", os.path.join(ROOT, "tools", "check_sgpr_hazard.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    asm = "\tv_readfirstlane_b32 s4, v1\n\tv_readfirstlane_b32 s5, v2\n{gap}\t;;#ASMSTART\n\tv_lshl_add_u64 v[0:1], v[0:1], 0, s[4:5]\n\t;;#ASMEND\n"
+    bad, n = mod.scan(asm.format(gap=""))
+    assert n == 1 and len(bad) == 2  # s5 written 0 and s4 written 1 wait state earlier
+    bad, n = mod.scan(asm.format(gap="\ts_nop 1\n"))
+    assert n == 1 and bad == []
+    bad, n = mod.scan(asm.format(gap="\tv_add_f32_e32 v3, v3, v3\n\tv_add_f32_e32 v3, v3, v3\n"))
+    assert bad == []
+    assert subprocess.call([sys.executable, os.path.join(ROOT, "tools", "check_sgpr_hazard.py")]) == 0
+
+
 def test_bench_starts_its_own_ranks_for_gpus_n(monkeypatch):
     """`python bench.py --gpus N` outside torchrun: N ranks are started as CHILD processes through torch.distributed.run on
     127.0.0.1 (this process has not imported torch or touched HIP at that point), with the caller's arguments passed on."""
