@@ -2014,6 +2014,25 @@ __global__ __launch_bounds__(256) void k_build_win_tables(CellTab* __restrict__ 
 }
 
 int vo_build_window_tables(vo_ctx* ctx) {
+    // the row pass of k_describe_tiled handles ONE group of four stream bytes in which the cells of a window differ: check that
+    // no window size needs more (the arithmetic of describe_cell_tab, on the host)
+    for (int win = 1; win <= kBigWin; win++) {
+        const double scale = (double)win / (kPatch + 1);
+        int nmin = 1 << 30, nmax = 0;
+        for (int c = 0; c <= kPatch; c++) {
+            const double fsx1 = c * scale, fsx2 = fsx1 + scale;
+            int sx1 = (int)std::ceil(fsx1), sx2 = (int)std::floor(fsx2);
+            sx2 = std::min(sx2, win - 1);
+            sx1 = std::min(sx1, sx2);
+            nmin = std::min(nmin, sx2 - sx1);
+            nmax = std::max(nmax, sx2 - sx1);
+        }
+        const int jm = std::max(4, 4 * ((nmin + 1) >> 2));
+        if (jm + 3 < nmax) {
+            fprintf(stderr, "vo_build_window_tables: window %d has cells of %d..%d pixels, more than one ragged group\n", win, nmin, nmax);
+            abort();
+        }
+    }
     VO_HIP(hipMalloc(&ctx->d_win_cell, (size_t)(kBigWin + 1) * (kPatch + 1) * sizeof(CellTab)));
     VO_HIP(hipMalloc(&ctx->d_win_pix, (size_t)(kBigWin + 1) * kWinTabPitch * sizeof(PixTab)));
     hipLaunchKernelGGL(k_build_win_tables, dim3(kBigWin), dim3(256), 0, ctx->stream, (CellTab*)ctx->d_win_cell, (PixTab*)ctx->d_win_pix);
@@ -2297,6 +2316,18 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                         rp_w1 = n >= 1 ? rp_am : 0.f, rp_w2 = n >= 2 ? rp_am : 0.f, rp_w3 = n >= 3 ? rp_am : 0.f;
                     }
                     const int rp_nmin = __builtin_amdgcn_readfirstlane(myct.pad) & 0xffff, rp_nmax = __builtin_amdgcn_readfirstlane(myct.pad) >> 16;
+                    // Stream bytes up to rp_nmin are full-weight pixels in every lane, and for every window size at most ONE more group
+                    // of four bytes holds pixels of some lanes (vo_build_window_tables checks it).  Its weights per lane - a_mid, or +0
+                    // past the lane's own count - are set up once per strip, and the group runs like the others (a compare and a
+                    // select per byte were 8 of a row's ~45 instructions in the <= 128 px class).
+                    const int rp_jm = max(4, 4 * ((rp_nmin + 1) >> 2));  // first stream byte of that group
+                    const bool rp_m1 = rp_jm <= rp_nmax;
+                    float rp_wm[4];
+                    {
+                        const int n = rp_sx2 - rp_s0 - 1;
+#pragma unroll
+                        for (int u = 0; u < 4; u++) rp_wm[u] = rp_jm + u <= n ? rp_am : 0.f;
+                    }
                     // lane = (row mod 3, cell).  The pixels a
                     // cell reads are contiguous - head (sx1 - 1), full-weight pixels [sx1, sx2), tail (sx2) - so they come in
                     // as a byte stream of ALIGNED words shifted into place (v_alignbyte): one LDS read per four pixels.  The
@@ -2307,7 +2338,6 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                     for (int rr = myrow; rr < nrw; rr += 3, p += 3 * kPitch, outp += 3 * (kPatch + 1)) {
                         const lds_u32* q = reinterpret_cast<const lds_u32*>(p + (rp_s0 & ~3));
                         const uint32_t rp_sh = (uint32_t)rp_s0;  // v_alignbyte uses bits [1:0]
-                        const int rp_n = rp_sx2 - rp_s0 - 1;
                         uint32_t lo = q[0], hi = q[1];
                         const int pt = p[rp_sx2];
                         uint32_t w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
@@ -2325,18 +2355,14 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                             acc += mul_byte_denorm<2>(w, rp_am);
                             acc += mul_byte_denorm<3>(w, rp_am);
                         }
-                        for (; j <= rp_nmax; j += 4, qi++) {  // lanes past their own count keep acc
+                        if (rp_m1) {  // j == rp_jm here; bytes past a lane's own count weigh +0
                             lo = hi;
                             hi = q[qi];
                             w = __builtin_amdgcn_alignbyte(hi, lo, rp_sh);
-                            const float a0 = acc + mul_byte_denorm<0>(w, rp_am);
-                            acc = j <= rp_n ? a0 : acc;
-                            const float a1 = acc + mul_byte_denorm<1>(w, rp_am);
-                            acc = j + 1 <= rp_n ? a1 : acc;
-                            const float a2 = acc + mul_byte_denorm<2>(w, rp_am);
-                            acc = j + 2 <= rp_n ? a2 : acc;
-                            const float a3 = acc + mul_byte_denorm<3>(w, rp_am);
-                            acc = j + 3 <= rp_n ? a3 : acc;
+                            acc += mul_byte_denorm<0>(w, rp_wm[0]);
+                            acc += mul_byte_denorm<1>(w, rp_wm[1]);
+                            acc += mul_byte_denorm<2>(w, rp_wm[2]);
+                            acc += mul_byte_denorm<3>(w, rp_wm[3]);
                         }
                         acc += mul_byte_denorm<0>((uint32_t)pt, rp_wt);  // tail, or +0
                         *outp = acc * 0x1p22f;
