@@ -2066,7 +2066,8 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
     constexpr int kOffSx = 0, kOffSy = kOffSx + WHI * 4;
     constexpr int kOffWin = (kOffSy + WHI * 4 + 15) & ~15, kOffRowv = (kOffWin + RS * kPitch + 15) & ~15;
     constexpr int kStripBytes = kOffRowv + NBUF * RS * (kPatch + 1) * 4, kGradBytes = 2 * kPatch * kPatch * 4;
-    __shared__ __attribute__((aligned(16))) unsigned char s_raw[kStripBytes > kGradBytes ? kStripBytes : kGradBytes];
+    // (+ 256 bytes: the vertical fold reads up to three rows past the last row of the strip buffer and discards them)
+    __shared__ __attribute__((aligned(16))) unsigned char s_raw[(kStripBytes > kGradBytes ? kStripBytes : kGradBytes) + 256];
     float* s_sx = reinterpret_cast<float*>(s_raw + kOffSx);   // start of every window row (sequential float accumulation)
     float* s_sy = reinterpret_cast<float*>(s_raw + kOffSy);
     uint8_t* s_win = s_raw + kOffWin;
@@ -2414,19 +2415,27 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                 };
                 fold_load();
                 const int r_end = min(i0 + RS, win);  // source rows [i0, r_end) are in this strip's buffer
-                const lds_f32* vcol = (const lds_f32*)s_rowv + (sidx * RS * (kPatch + 1) + f_dx) - i0 * (kPatch + 1);  // row q at vcol[q * 21]
+                // row q of the strip buffer at byte vcol + 84 q.  (Index products written as 24-bit multiplies and a running pointer: left
+                // to itself the compiler turns every `vcol[q * 21]` into a quarter-rate v_mad_u64_u32, eight per destination row.)
+                constexpr int kRowB = (kPatch + 1) * 4;
+                const lds_u8* vcol = (const lds_u8*)((const lds_f32*)s_rowv + (sidx * RS * (kPatch + 1) + f_dx)) - i0 * kRowB;
+                auto vrow = [&](int q) { return (const lds_f32*)(vcol + __mul24(q, kRowB)); };
                 while (f_first < r_end) {
                     int q = max(f_first, i0);
+                    const lds_f32* pq = vrow(q);
                     float acc = f_carry;
                     if (q == f_first) {  // the row begins here: OpenCV assigns beta * buf to the open sum
-                        acc = f_wfirst * vcol[q * (kPatch + 1)];
+                        acc = f_wfirst * pq[0];
                         q++;
+                        pq += kPatch + 1;
                     }
                     const int qm = min(f_sx2, r_end);  // full-weight rows [q, qm), four reads in flight, adds in row order
-                    for (; q < qm; q += 4) {
+                    for (; q < qm; q += 4, pq += 4 * (kPatch + 1)) {
+                        // (rows at and past qm are read too - at most three rows past the strip's last, inside the workgroup's LDS -
+                        // and not added)
                         float v[4];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) v[u] = vcol[min(q + u, qm - 1) * (kPatch + 1)];
+                        for (int u = 0; u < 4; u++) v[u] = pq[u * (kPatch + 1)];
 #pragma unroll
                         for (int u = 0; u < 4; u++) {
                             const float a = acc + f_amid * v[u];
@@ -2435,11 +2444,11 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
                     }
                     q = max(min(q, qm), min(f_first + 1, r_end));  // the row after the last one added
                     if (f_tail && q == f_sx2 && q < r_end) {
-                        acc += f_atail * vcol[q * (kPatch + 1)];
+                        acc += f_atail * *vrow(q);
                         q++;
                     }
                     if (q > f_last) {  // destination row complete
-                        s_patch[f_d * (kPatch + 1) + f_dx] = (uint8_t)saturate_u8(d_cvRoundF(acc));
+                        s_patch[__mul24(f_d, kPatch + 1) + f_dx] = (uint8_t)saturate_u8(d_cvRoundF(acc));
                         f_d += 3;
                         f_carry = 0.f;
                         fold_load();
