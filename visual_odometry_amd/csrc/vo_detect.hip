@@ -2013,6 +2013,20 @@ __global__ __launch_bounds__(256) void k_build_win_tables(CellTab* __restrict__ 
     for (int j = tid; j < win; j += 256) g_pix[(size_t)win * kWinTabPitch + j] = s_pix[j];
 }
 
+// The descriptor sampler and the row pass multiply pixel bytes as DENORMAL floats (mul_byte_denorm): correct only while the
+// kernels run with IEEE f32 denormals (the compiler's default for HIP; -fgpu-flush-denormals-to-zero or a fast-math build
+// would silently turn every product into zero).  Checked once per context, on the device, before anything depends on it.
+__global__ __launch_bounds__(64) void k_denorm_selfcheck(int* __restrict__ ok) {
+    const uint32_t t = threadIdx.x;
+    const uint32_t q = t | ((t + 64u) << 8) | ((t + 128u) << 16) | ((t + 192u) << 24);
+    const float w = 0.75f * 0x1p127f;
+    const bool good = mul_byte_denorm<0>(q, w) * 0x1p22f == (float)t * 0.75f && mul_byte_denorm<1>(q, w) * 0x1p22f == (float)(t + 64u) * 0.75f &&
+                      mul_byte_denorm<2>(q, w) * 0x1p22f == (float)(t + 128u) * 0.75f &&
+                      mul_byte_denorm<3>(q, w) * 0x1p22f == (float)(t + 192u) * 0.75f;
+    const unsigned long long m = __ballot(good);
+    if (t == 0) *ok = m == ~0ull ? 1 : 0;
+}
+
 int vo_build_window_tables(vo_ctx* ctx) {
     // the row pass of k_describe_tiled handles ONE group of four stream bytes in which the cells of a window differ: check that
     // no window size needs more (the arithmetic of describe_cell_tab, on the host)
@@ -2037,7 +2051,16 @@ int vo_build_window_tables(vo_ctx* ctx) {
     VO_HIP(hipMalloc(&ctx->d_win_pix, (size_t)(kBigWin + 1) * kWinTabPitch * sizeof(PixTab)));
     hipLaunchKernelGGL(k_build_win_tables, dim3(kBigWin), dim3(256), 0, ctx->stream, (CellTab*)ctx->d_win_cell, (PixTab*)ctx->d_win_pix);
     VO_HIP(hipGetLastError());
+    // (the first word of the pixel table doubles as the self-check's flag: window size 0 has no entries)
+    hipLaunchKernelGGL(k_denorm_selfcheck, dim3(1), dim3(64), 0, ctx->stream, (int*)ctx->d_win_pix);
+    VO_HIP(hipGetLastError());
+    int denorm_ok = 0;
+    VO_HIP(hipMemcpyAsync(&denorm_ok, ctx->d_win_pix, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
     VO_HIP(hipStreamSynchronize(ctx->stream));
+    if (!denorm_ok) {
+        vo_set_error_text("f32 denormals are flushed in this build of the library: the descriptor kernels need IEEE denormals");
+        return VO_ERR_UNSUPPORTED;
+    }
     return VO_OK;
 }
 
