@@ -1631,6 +1631,16 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
 __device__ __forceinline__ void orientation_pair(const int32_t* __restrict__ sum, int sw, int H, int W, vo_keypoint* kpp, bool valid,
                                                  int lane, float2* s_XY, int* s_A) {
     const int l32 = lane & 31;
+    // the sample pattern of this lane's four passes - the same for every keypoint - is requested before the keypoint record
+    // (indexed per lane, the constant table comes through vector loads: one round trip less in front of every pass) and the
+    // passes are unrolled: 1.70 -> 1.55 ms per 128 frames.  (The taps of pass p + 1 requested before the arithmetic of pass p
+    // as well: 1.54, not kept.)
+    float tpx[4], tpy[4], tpw[4];
+#pragma unroll
+    for (int pass = 0; pass < 4; pass++) {
+        const int kk = min(pass * 32 + l32, kOriSamples - 1);
+        tpx[pass] = c_tab.aptx[kk], tpy[pass] = c_tab.apty[kk], tpw[pass] = c_tab.aptw[kk];
+    }
     const float cx = valid ? kpp->x : 0.f, cy = valid ? kpp->y : 0.f;
     const float s = (valid ? kpp->size : 9.f) * 1.2f / 9.0f;
     const int g = 2 * d_cvRoundF(2 * s);
@@ -1647,14 +1657,15 @@ __device__ __forceinline__ void orientation_pair(const int32_t* __restrict__ sum
         const float wxa = -1.f / ((float)xm * g), wxb = 1.f / ((float)(g - xm) * g);
         const float wya = 1.f / ((float)g * xm), wyb = -1.f / ((float)g * (g - xm));
         const float half = (float)(g - 1) / 2;
+#pragma unroll
         for (int pass = 0; pass < 4; pass++) {
             const int kk = pass * 32 + l32;
             bool inb = false;
             float X = 0, Y = 0;
             int Ar = 0;
             if (fits && kk < kOriSamples) {
-                const int x = d_cvRoundF(cx + c_tab.aptx[kk] * s - half);
-                const int y = d_cvRoundF(cy + c_tab.apty[kk] * s - half);
+                const int x = d_cvRoundF(cx + tpx[pass] * s - half);
+                const int y = d_cvRoundF(cy + tpy[pass] * s - half);
                 inb = !(y < 0 || y >= H + 1 - g || x < 0 || x >= W + 1 - g);
                 if (inb) {
                     const int32_t* p = sum + (size_t)y * sw + x;
@@ -1669,7 +1680,7 @@ __device__ __forceinline__ void orientation_pair(const int32_t* __restrict__ sum
                     d = (double)((float)bya * wya);
                     d += (double)((float)byb * wyb);
                     const float vy = (float)d;
-                    const float w = c_tab.aptw[kk];
+                    const float w = tpw[pass];
                     X = vx * w;
                     Y = vy * w;
                     Ar = d_cvRoundF(d_fastAtan2(Y, X));
