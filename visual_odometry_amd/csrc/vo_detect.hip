@@ -2176,9 +2176,10 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
         const int win = (int)((kPatch + 1) * s);
         const uint8_t* __restrict__ img = img_base + (size_t)frame * img_stride;
         const uint32_t* __restrict__ quad = quad_base + (size_t)frame * quad_stride(H, W);
-        const double scale = (double)win / (kPatch + 1);
-        const int iscale = d_cvRoundD(scale);
-        const bool area_fast = fabs(scale - iscale) < DBL_EPSILON;
+        // scale = win / 21 in double, iscale = cvRound(scale), area_fast = |scale - iscale| < DBL_EPSILON (INTER_AREA's integer-scale
+        // branch): win / 21 is an integer iff 21 divides win and never lies halfway between two - in integers, without the division
+        const int iscale = (2 * win + (kPatch + 1)) / (2 * (kPatch + 1));
+        const bool area_fast = win % (kPatch + 1) == 0;
         // the window size's decimation tables (k_build_win_tables)
         if (!area_fast && tid <= kPatch) s_cell[tid] = g_cell[(size_t)win * (kPatch + 1) + tid];
         if (tid == 0) n_code = *(volatile const int*)&list[min(n_item, n_items - 1)];  // look-ahead stage 2: list entry
