@@ -170,6 +170,28 @@ def test_large_windows_across_the_frame_border(ctx, seed):
     assert len(bad) == 0, (len(bad), len(k), bad[:10], win[bad[:10]])
 
 
+def test_frame_wider_than_the_closed_form_bound(ctx):
+    """A 300 x 7400 panorama strip: window coordinates beyond 7000 are outside the range in which the tiled sampler's closed form
+    (and its 32.32 fixed-point walk) is proven exact, so keypoints out there take the sequential walk of the fallback kernel;
+    on both sides of the bound the descriptors must be the oracle's."""
+    rng = np.random.default_rng(77)
+    h, w = 300, 7400
+    img = np.full((h, w), 100.0, np.float32)
+    yy, xx = np.mgrid[0:h, 0:w].astype(np.float32)
+    for cx in np.concatenate([rng.uniform(20, w - 20, 120), rng.uniform(6900, w - 10, 60)]):
+        cy, sg = rng.uniform(15, h - 15), rng.uniform(1.6, 9.0)
+        x0, x1 = int(max(cx - 6 * sg, 0)), int(min(cx + 6 * sg, w))
+        img[:, x0:x1] += rng.uniform(-70, 110) * np.exp(-((yy[:, x0:x1] - cy) ** 2 + (xx[:, x0:x1] - cx) ** 2) / (2 * sg * sg))
+    img = np.clip(img + rng.normal(0, 1.5, size=img.shape), 0, 255).astype(np.uint8)
+    k, d = ctx.detect_describe(img)
+    rk, rd = O.detect_describe(img)
+    _assert_kps_equal(k, rk)
+    assert (k["x"] > 7050).sum() > 10 and (k["x"] < 6900).sum() > 50, ((k["x"] > 7050).sum(), len(k))
+    assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+    bad = np.flatnonzero((d.view(np.uint32) != rd.view(np.uint32)).any(axis=1))
+    assert len(bad) == 0, (len(bad), len(k), bad[:10], k["x"][bad[:10]])
+
+
 def test_uniform_image_has_no_keypoints(ctx):
     img = np.full((200, 300), 77, np.uint8)
     k, d = ctx.detect_describe(img)
