@@ -309,6 +309,35 @@ def test_surf_parameter_variants(ctx, n_oct, upright):
         c.close()
 
 
+@pytest.mark.parametrize("thr", [0.0, 400.0, 6000.0])
+def test_hessian_threshold_variants(ctx, thr):
+    """minHessian (camera_utility.hpp:33) is a mutable global of the reference: a threshold of 0 keeps every positive local
+    maximum (several times the default's keypoints), a high one keeps a handful; the survivors of a higher threshold are a
+    subset of the default run's, with identical records and descriptors."""
+    from visual_odometry_amd.frontend import Context, default_params
+
+    p = default_params()
+    p.hessian_threshold = thr
+    c = Context(p)
+    try:
+        sc = _scene(480, 640, 700, 1001)
+        k, d = c.detect_describe(sc.img1, cap=1 << 16)
+        rk, rd = O.detect_describe(sc.img1, params=p)
+        _assert_kps_equal(k, rk)
+        assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+        assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+        k50, d50 = ctx.detect_describe(sc.img1)
+        if thr == 0.0:
+            assert len(k) > len(k50)
+        else:
+            keep = k50["response"] > thr  # the reference's test is `val0 > hessianThreshold`
+            assert 0 < keep.sum() < len(k50)
+            _assert_kps_equal(k, k50[keep])
+            assert np.array_equal(d.view(np.uint32), d50[keep].view(np.uint32))
+    finally:
+        c.close()
+
+
 def test_unsupported_surf_variants_are_refused():
     from visual_odometry_amd.frontend import Context, VoError, default_params
 
