@@ -27,7 +27,8 @@ void integral_u8(const uint8_t* img, int rows, int cols, size_t step, int32_t* s
 void layer_geometry(int rows, int cols, int octave, int layer, int* size, int* step, int* lrows, int* lcols);
 void calc_layer_det_trace(const int32_t* sum, int rows, int cols, int size, int sampleStep, float* det, float* trace);
 extern float g_forced_dir;  // test hook, oracle_surf.cpp
-void fast_hessian(const int32_t* sum, int rows, int cols, float hessianThreshold, std::vector<vo_keypoint>& kps, int nOctaves = 4);
+void fast_hessian(const int32_t* sum, int rows, int cols, float hessianThreshold, std::vector<vo_keypoint>& kps, int nOctaves = 4,
+                  int nOctaveLayers = 3);
 void gaussian_kernel_f32(int n, double sigma, float* cf);
 float fastAtan2(float y, float x);
 void resize_area_u8(const uint8_t* win, int ssize, uint8_t* dst, int dsize);

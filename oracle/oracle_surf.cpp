@@ -153,10 +153,11 @@ static bool keypointGreater(const vo_keypoint& a, const vo_keypoint& b) {
     return a.x < b.x;
 }
 
-// fastHessianDetector (A.2-A.4), nOctaveLayers=3; nOctaves is the reference's 4 unless the caller asks for fewer (the octaves
-// are independent of each other: fewer octaves = the same keypoints without those of the dropped octaves)
-void fast_hessian(const int32_t* sum, int rows, int cols, float hessianThreshold, std::vector<vo_keypoint>& kps, int nOctaves) {
-    const int nOctaveLayers = 3;
+// fastHessianDetector (A.2-A.4).  nOctaves / nOctaveLayers are the reference's 4 / 3 (camera_utility.hpp:35-36) unless the
+// caller asks otherwise (the octaves are independent of each other: fewer octaves = the same keypoints without those of the
+// dropped octaves; the layer loops below are A.2's, written for any layer count)
+void fast_hessian(const int32_t* sum, int rows, int cols, float hessianThreshold, std::vector<vo_keypoint>& kps, int nOctaves,
+                  int nOctaveLayers) {
     const int nTotal = (nOctaveLayers + 2) * nOctaves;
     std::vector<std::vector<float>> dets(nTotal), traces(nTotal);
     std::vector<int> sizes(nTotal), steps(nTotal);
@@ -534,7 +535,7 @@ void detect_describe(const vo_params& P, const uint8_t* img, int rows, int cols,
                      std::vector<vo_keypoint>& kps, std::vector<float>* desc) {
     std::vector<int32_t> sum((size_t)(rows + 1) * (cols + 1));
     integral_u8(img, rows, cols, step, sum.data());
-    fast_hessian(sum.data(), rows, cols, P.hessian_threshold, kps, P.n_octaves);
+    fast_hessian(sum.data(), rows, cols, P.hessian_threshold, kps, P.n_octaves, P.n_octave_layers);
     if (!desc) return;
     static const InvokerTables T;
     const int N = (int)kps.size();

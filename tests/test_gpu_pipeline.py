@@ -776,13 +776,15 @@ def test_pair_batch_from_python_matches_the_batch_api(ctx):
         e.close()
 
 
-def test_batch_with_surf_variants_equals_the_single_calls_and_the_oracle():
+@pytest.mark.parametrize("n_oct,n_layers,upright", [(3, 3, 1), (4, 4, 0), (4, 2, 0)])
+def test_batch_with_surf_variants_equals_the_single_calls_and_the_oracle(n_oct, n_layers, upright):
     """vo_params.n_octaves = 3 and upright through the batch path (the octave-1 launch stays, octave 3's tiles are gone, every
-    keypoint is described by the sequential kernel): records and matches equal the synchronous calls and the oracle."""
+    keypoint is described by the sequential kernel), and layer counts other than 3 (the plain det-plane / NMS kernels in place of
+    the two fused launches, all frames of the batch in one group): records and matches equal the synchronous calls and the oracle."""
     from visual_odometry_amd.frontend import Context, default_params
 
     p = default_params()
-    p.n_octaves, p.upright = 3, 1
+    p.n_octaves, p.n_octave_layers, p.upright = n_oct, n_layers, upright
     c = Context(p)
     try:
         scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 21), (400, 22), (900, 23)]]

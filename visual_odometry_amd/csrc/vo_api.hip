@@ -221,7 +221,7 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
     else
         vo_params_default(&p);
     // supported: the reference's values (4, 3, false, false); fewer octaves; upright.  Not: other layer counts, 128-float descriptors
-    if (p.n_octaves < 1 || p.n_octaves > 4 || p.n_octave_layers != 3 || p.extended) return VO_ERR_UNSUPPORTED;
+    if (p.n_octaves < 1 || p.n_octaves > 4 || p.n_octave_layers < 1 || p.n_octave_layers > kMaxOctaveLayers || p.extended) return VO_ERR_UNSUPPORTED;
     p.upright = p.upright ? 1 : 0;
     if (p.kp_capacity < 64 || p.match_capacity < 8 || p.ransac_max_iters < 1 || p.ransac_max_iters > kMaxHyp)
         return VO_ERR_INVALID_ARG;
@@ -292,6 +292,7 @@ extern "C" void vo_ctx_destroy(vo_ctx* ctx) {
     vo_pairset_free(ctx->ps);
     vo_geometry_release(ctx);
     if (ctx->d_tmp) hipFree(ctx->d_tmp);
+    if (ctx->d_gen) hipFree(ctx->d_gen);
     if (ctx->h_up) hipHostFree(ctx->h_up);
     if (ctx->h_down) hipHostFree(ctx->h_down);
     if (ctx->d_win_cell) hipFree(ctx->d_win_cell);

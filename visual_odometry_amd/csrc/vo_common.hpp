@@ -31,6 +31,7 @@ void vo_set_error_text(const char* text);  // what vo_last_hip_error() returns n
 constexpr int kNumOctaves = 4;
 constexpr int kLayersPerOctave = 5;  // nOctaveLayers + 2
 constexpr int kNumLayers = kNumOctaves * kLayersPerOctave;
+constexpr int kMaxOctaveLayers = 6;  // vo_params.n_octave_layers 1..6 (3 = the reference's, the LDS-tile kernels; others: plain kernels)
 constexpr int kOriSamples = 113;  // lattice points with i^2 + j^2 <= 36 (SURVEY A.5 says 109; the loop it quotes yields 113)
 constexpr int kPatch = 20;        // PATCH_SZ
 constexpr int kMaxHyp = 4096;     // largest max_iters accepted (BASELINE config 5)
@@ -223,6 +224,8 @@ struct vo_ctx {
     PairSet ps;
     void* d_tmp = nullptr;
     size_t d_tmp_bytes = 0;
+    void* d_gen = nullptr;          // det planes of the n_octave_layers != 3 detector (vo_detect.hip), grown on demand
+    size_t d_gen_bytes = 0;
     // pinned bounce buffers of the synchronous entry points: frames go up and results come down through them (a copy
     // between the device and PAGEABLE memory makes the runtime pin the caller's pages for every call: ~4 ms per frame pair)
     uint8_t* h_up = nullptr;

@@ -78,46 +78,54 @@ constexpr BoxWeights box_weights(int size) {
     return r;
 }
 
+// Box pattern of one layer of the given size (resizeHaarPattern): corners cvRound(size/9 * v) in float, weights
+// sign / ((float)(dx2 - dx1) * (dy2 - dy1)).  Any size: the n_octave_layers != 3 path builds its layers with it too.
+static LayerTab make_layer_tab(int size, int step) {
+    LayerTab L;
+    std::memset(&L, 0, sizeof(L));
+    L.size = size;
+    L.step = step;
+    L.margin = (size / 2) / step;
+    const float ratio = (float)size / 9;
+    auto R = [&](int v) { return h_cvRoundF(ratio * v); };
+    const int ex[4] = {R(0), R(3), R(6), R(9)};
+    const int e27[2] = {R(2), R(7)};
+    const int c[4] = {R(1), R(4), R(5), R(8)};
+    for (int k = 0; k < 4; k++) {
+        L.xdx[k] = ex[k];
+        L.ydy[k] = ex[k];
+        L.cxy[k] = c[k];
+    }
+    for (int k = 0; k < 2; k++) {
+        L.ydx[k] = e27[k];
+        L.xdy[k] = e27[k];
+    }
+    const float wsgn[3] = {1, -2, 1};
+    for (int k = 0; k < 3; k++) {
+        // w = src[4] / ((float)(dx2-dx1) * (dy2-dy1))
+        L.w[k] = wsgn[k] / ((float)(ex[k + 1] - ex[k]) * (e27[1] - e27[0]));
+        L.w[3 + k] = wsgn[k] / ((float)(e27[1] - e27[0]) * (ex[k + 1] - ex[k]));
+    }
+    const int bx[4] = {0, 2, 0, 2}, by[4] = {0, 0, 2, 2};
+    const float ws[4] = {1, -1, -1, 1};
+    for (int k = 0; k < 4; k++) L.w[6 + k] = ws[k] / ((float)(c[bx[k] + 1] - c[bx[k]]) * (c[by[k] + 1] - c[by[k]]));
+    return L;
+}
+
 void vo_build_detect_tables(DetectTables& t, int) {
     std::memset(&t, 0, sizeof(t));
     for (int o = 0; o < kNumOctaves; o++)
         for (int l = 0; l < kLayersPerOctave; l++) {
             LayerTab& L = t.layers[o * kLayersPerOctave + l];
-            L.size = (9 + 6 * l) << o;
-            L.step = 1 << o;
-            L.margin = (L.size / 2) / L.step;
-            float ratio = (float)L.size / 9;
-            auto R = [&](int v) { return h_cvRoundF(ratio * v); };
-            const int ex[4] = {R(0), R(3), R(6), R(9)};
-            const int e27[2] = {R(2), R(7)};
-            const int c[4] = {R(1), R(4), R(5), R(8)};
-            for (int k = 0; k < 4; k++) {
-                L.xdx[k] = ex[k];
-                L.ydy[k] = ex[k];
-                L.cxy[k] = c[k];
-            }
-            for (int k = 0; k < 2; k++) {
-                L.ydx[k] = e27[k];
-                L.xdy[k] = e27[k];
-            }
+            L = make_layer_tab((9 + 6 * l) << o, 1 << o);
             {   // the integer form used for compile-time box corners (box_geom) must agree with the float rounding
-                const int v[10] = {R(0), R(1), R(2), R(3), R(4), R(5), R(6), R(7), R(8), R(9)};
+                const float ratio = (float)L.size / 9;
                 for (int k = 0; k < 10; k++)
-                    if (v[k] != (2 * L.size * k + 9) / 18) {
+                    if (h_cvRoundF(ratio * k) != (2 * L.size * k + 9) / 18) {
                         std::fprintf(stderr, "vo_mi355x: box corner table mismatch (size %d, v %d)\n", L.size, k);
                         std::abort();
                     }
             }
-            const float wsgn[3] = {1, -2, 1};
-            for (int k = 0; k < 3; k++) {
-                // w = src[4] / ((float)(dx2-dx1) * (dy2-dy1))
-                L.w[k] = wsgn[k] / ((float)(ex[k + 1] - ex[k]) * (e27[1] - e27[0]));
-                L.w[3 + k] = wsgn[k] / ((float)(e27[1] - e27[0]) * (ex[k + 1] - ex[k]));
-            }
-            const int bx[4] = {0, 2, 0, 2}, by[4] = {0, 0, 2, 2};
-            const float ws[4] = {1, -1, -1, 1};
-            for (int k = 0; k < 4; k++)
-                L.w[6 + k] = ws[k] / ((float)(c[bx[k] + 1] - c[bx[k]]) * (c[by[k] + 1] - c[by[k]]));
             const BoxWeights cw = box_weights(L.size);  // what the LDS-tile kernels use as literals
             if (std::memcmp(cw.w, L.w, sizeof(cw.w)) != 0) {
                 std::fprintf(stderr, "vo_mi355x: box weight table mismatch (size %d)\n", L.size);
@@ -1054,6 +1062,161 @@ __global__ __launch_bounds__(NTH) void k_hessian_nms_lds(const int32_t* __restri
 }
 
 // ------------------------------------------------------------------------------------------------
+// a2 + a3 for n_octave_layers != 3.  The reference fixes three layers per octave (camera_utility.hpp:36, a mutable global), and the
+// kernels above are built for exactly that pyramid (five planes per tile in LDS, box weights as literals).  Any other layer count
+// takes this plain form of calcLayerDetAndTrace / findMaximaInLayer: the det planes of one octave are
+// materialised for a group of frames, one launch per layer, and one launch per middle layer does the 3 x 3 x 3 test, the
+// interpolation and the append.  Same arithmetic, same keypoints as the oracle's; correctness path, no LDS form.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_hessian_plane_g(const int32_t* __restrict__ sum_base, size_t sum_stride, int frame0, int H,
+                                                         int W, LayerTab L, float* __restrict__ det, size_t frame_stride) {
+    const int lrows = H / L.step, lcols = W / L.step;
+    const int j = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (i >= lrows || j >= lcols) return;
+    const int32_t* __restrict__ sum = sum_base + (size_t)(frame0 + blockIdx.z) * sum_stride;
+    float dv = 0.f;
+    if (L.size <= H && L.size <= W) {
+        const int samples_i = 1 + (H - L.size) / L.step, samples_j = 1 + (W - L.size) / L.step;
+        const int oi = i - L.margin, oj = j - L.margin;
+        if (oi >= 0 && oj >= 0 && oi < samples_i && oj < samples_j) {
+            float dx, dy, dxy;
+            hessian_boxes(L, sum + (size_t)(oi * L.step) * (W + 1) + oj * L.step, W + 1, dx, dy, dxy);
+            dv = hessian_det(dx, dy, dxy);
+        }
+    }
+    det[(size_t)blockIdx.z * frame_stride + (size_t)i * lcols + j] = dv;
+}
+
+// det: the middle layer's plane of frame frame0 + blockIdx.z; the layers below and above lie one plane (lrows * lcols) before / after
+__global__ __launch_bounds__(256) void k_nms_g(const float* __restrict__ det, size_t frame_stride, LayerTab L, int size_prev,
+                                               int size_next, int o, int H, int W, float thr, const int32_t* __restrict__ sum_base,
+                                               size_t sum_stride, int frame0, vo_keypoint* __restrict__ kp_base, int cap,
+                                               FrameCounters* __restrict__ cnt, int filter_invalid) {
+    const int step = L.step, sw = W + 1;
+    const int lrows = H / step, lcols = W / step;
+    const int lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 64 + lane;
+    const int i = blockIdx.y * 4 + (threadIdx.x >> 6);
+    const int frame = frame0 + blockIdx.z;
+    const int margin = (size_next / 2) / step + 1;
+    const size_t plane = (size_t)lrows * lcols;
+    bool emit = false;
+    vo_keypoint kpt;
+    if (i >= margin && i < lrows - margin && j >= margin && j < lcols - margin) {
+        const float* __restrict__ c = det + (size_t)blockIdx.z * frame_stride + (size_t)i * lcols + j;
+        const float val0 = c[0];
+        if (val0 > thr) {
+            float N9[3][9];
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int t = 0; t < 9; t++) N9[a][t] = c[((ptrdiff_t)a - 1) * (ptrdiff_t)plane + (t / 3 - 1) * lcols + (t % 3 - 1)];
+            bool is_max = true;
+#pragma unroll
+            for (int a = 0; a < 3; a++)
+#pragma unroll
+                for (int t = 0; t < 9; t++)
+                    if (!(a == 1 && t == 4)) is_max = is_max && (val0 > N9[a][t]);
+            if (is_max) {
+                const int size = L.size;
+                const int sum_i = step * (i - (size / 2) / step);
+                const int sum_j = step * (j - (size / 2) / step);
+                const float center_i = sum_i + (size - 1) * 0.5f;
+                const float center_j = sum_j + (size - 1) * 0.5f;
+                // interpolateKeypoint, Cramer's rule in float
+                const float b0 = -(N9[1][5] - N9[1][3]) / 2;
+                const float b1 = -(N9[1][7] - N9[1][1]) / 2;
+                const float b2 = -(N9[2][4] - N9[0][4]) / 2;
+                const float a00 = N9[1][3] - 2 * N9[1][4] + N9[1][5];
+                const float a01 = (N9[1][8] - N9[1][6] - N9[1][2] + N9[1][0]) / 4;
+                const float a02 = (N9[2][5] - N9[2][3] - N9[0][5] + N9[0][3]) / 4;
+                const float a10 = a01;
+                const float a11 = N9[1][1] - 2 * N9[1][4] + N9[1][7];
+                const float a12 = (N9[2][7] - N9[2][1] - N9[0][7] + N9[0][1]) / 4;
+                const float a20 = a02, a21 = a12;
+                const float a22 = N9[0][4] - 2 * N9[1][4] + N9[2][4];
+                float d = a00 * (a11 * a22 - a21 * a12) - a01 * (a10 * a22 - a20 * a12) + a02 * (a10 * a21 - a20 * a11);
+                float x0 = 0, x1 = 0, x2 = 0;
+                if (d != 0) {
+                    d = 1 / d;
+                    x0 = d * (b0 * (a11 * a22 - a12 * a21) - a01 * (b1 * a22 - a12 * b2) + a02 * (b1 * a21 - a11 * b2));
+                    x1 = d * (a00 * (b1 * a22 - a12 * b2) - b0 * (a10 * a22 - a12 * a20) + a02 * (a10 * b2 - b1 * a20));
+                    x2 = d * (a00 * (a11 * b2 - b1 * a21) - a01 * (a10 * b2 - b1 * a20) + b0 * (a10 * a21 - a11 * a20));
+                }
+                const bool ok = (x0 != 0 || x1 != 0 || x2 != 0) && fabsf(x0) <= 1 && fabsf(x1) <= 1 && fabsf(x2) <= 1;
+                if (ok) {
+                    const int ds = size - size_prev;
+                    kpt.x = center_j + x0 * step;
+                    kpt.y = center_i + x1 * step;
+                    kpt.size = (float)d_cvRoundF((float)size + x2 * ds);
+                    kpt.angle = -1.f;
+                    kpt.response = val0;
+                    kpt.octave = o;
+                    float dx, dy, dxy;  // the trace at the same sample (not materialised)
+                    const int32_t* __restrict__ sum = sum_base + (size_t)frame * sum_stride;
+                    hessian_boxes(L, sum + (size_t)((i - L.margin) * step) * sw + (j - L.margin) * step, sw, dx, dy, dxy);
+                    const float tr = dx + dy;
+                    kpt.class_id = (tr > 0) - (tr < 0);
+                    emit = !filter_invalid || kp_describable(kpt.x, kpt.y, kpt.size, H, W, filter_invalid == 2);
+                }
+            }
+        }
+    }
+    const unsigned long long m = __ballot(emit);
+    if (m) {
+        int base = 0;
+        if (lane == 0) base = atomicAdd(&cnt[frame].n_raw, __popcll(m));
+        base = __shfl(base, 0, 64);
+        if (emit) {
+            const int pos = base + __popcll(m & ((1ull << lane) - 1ull));
+            if (pos < cap) kp_base[(size_t)frame * cap + pos] = kpt;
+        }
+    }
+}
+
+static int enqueue_hessian_nms_generic(vo_ctx* ctx, FrameSet& fs, bool describe) {
+    const int nl = ctx->prm.n_octave_layers, n_oct = ctx->prm.n_octaves;
+    const int filter_mode = describe ? (ctx->prm.upright ? 2 : 1) : 0;
+    // det planes of ONE octave for a group of frames; the buffer is bounded (2 GB) and grows with the context
+    const size_t per_frame0 = (size_t)(nl + 2) * fs.H * fs.W;  // floats, octave 0
+    if (per_frame0 == 0) return VO_OK;
+    const size_t budget = (size_t)1 << 29;  // floats
+    const int group = (int)std::min<size_t>((size_t)fs.F, std::max<size_t>(1, budget / per_frame0));
+    const size_t need = per_frame0 * group * sizeof(float);
+    if (need > ctx->d_gen_bytes) {
+        if (ctx->d_gen) VO_HIP(hipFree(ctx->d_gen));  // (synchronises: nothing still reads the old buffer)
+        ctx->d_gen = nullptr;
+        ctx->d_gen_bytes = 0;
+        VO_HIP(hipMalloc(&ctx->d_gen, need));
+        ctx->d_gen_bytes = need;
+    }
+    float* det = (float*)ctx->d_gen;
+    StageScope sc(ctx, ST_HESSIAN_OCT0);
+    for (int f0 = 0; f0 < fs.F; f0 += group) {
+        const int nf = std::min(group, fs.F - f0);
+        for (int o = 0; o < n_oct; o++) {
+            const int step = 1 << o, lrows = fs.H / step, lcols = fs.W / step;
+            if (lrows <= 0 || lcols <= 0) continue;
+            const size_t plane = (size_t)lrows * lcols, frame_stride = plane * (nl + 2);
+            const dim3 g((lcols + 63) / 64, (lrows + 3) / 4, nf);
+            std::vector<LayerTab> tabs(nl + 2);
+            for (int l = 0; l < nl + 2; l++) {
+                tabs[l] = make_layer_tab((9 + 6 * l) << o, step);
+                hipLaunchKernelGGL(k_hessian_plane_g, g, dim3(256), 0, ctx->stream, fs.sum, fs.sum_stride(), f0, fs.H, fs.W, tabs[l],
+                                   det + (size_t)l * plane, frame_stride);
+            }
+            for (int l = 1; l <= nl; l++)
+                hipLaunchKernelGGL(k_nms_g, g, dim3(256), 0, ctx->stream, det + (size_t)l * plane, frame_stride, tabs[l], tabs[l - 1].size,
+                                   tabs[l + 1].size, o, fs.H, fs.W, ctx->prm.hessian_threshold, fs.sum, fs.sum_stride(), f0, fs.kp_raw,
+                                   fs.cap, fs.cnt, filter_mode);
+        }
+    }
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 // a4: KeypointGreater rank sort.  rank[i] = #{j : kp_j > kp_i}; the order is total, so ranks
 // are a permutation and the scatter is deterministic whatever order NMS appended in.
 // ------------------------------------------------------------------------------------------------
@@ -1175,6 +1338,7 @@ __global__ __launch_bounds__(1024) void k_sort_bitonic(const vo_keypoint* __rest
 constexpr int kSmallWin = 128;  // windows up to 128 px use the 11 KB LDS instance
 constexpr int kMidWin = 320;
 constexpr int kBigWin = 768;    // largest window: 21 * 1.2/9 * (216 + 48) = 739
+constexpr int kHugeWin = 1152;  // n_octave_layers up to kMaxOctaveLayers = 6: 21 * 1.2/9 * (360 + 48) = 1142 (sequential kernel only)
 
 struct CellTab {  // one destination cell of the INTER_AREA decimation table
     int sx1, sx2;         // full-weight source range [sx1, sx2)
@@ -2525,7 +2689,9 @@ __global__ __launch_bounds__(NW * 64) __attribute__((amdgpu_waves_per_eu(WHI > 3
 __device__ __forceinline__ int classify_key(const vo_keypoint& kp, int frame, int W, int nbins, int* cls) {
     const float s = kp.size * 1.2f / 9.0f;
     const int win = (int)((kPatch + 1) * s);
-    *cls = win <= 64 ? 0 : (win <= kSmallWin ? 1 : (win <= kMidWin ? 2 : 3));
+    // (class 4: windows beyond the tiled kernels' tables - they exist only with more than three layers per octave - go straight
+    // to the sequential kernel's list)
+    *cls = win <= 64 ? 0 : (win <= kSmallWin ? 1 : (win <= kMidWin ? 2 : (win <= kBigWin ? 3 : 4)));
     const int bx = min(max((int)kp.x, 0), W - 1) >> 8, by = max((int)kp.y, 0) >> 8;
     const int bins_x = (W + 255) >> 8;
     return frame * nbins + min(by * bins_x + bx, nbins - 1);
@@ -2540,7 +2706,7 @@ __global__ __launch_bounds__(256) void k_classify_count(const vo_keypoint* __res
     int cls;
     const vo_keypoint kp = kp_base[(size_t)frame * cap + k];
     const int key = classify_key(kp, frame, W, nbins, &cls);
-    atomicAdd(&hist[cls * nkeys + key], 1);
+    if (cls < 4) atomicAdd(&hist[cls * nkeys + key], 1);
     // sin / cos of the descriptor direction, one keypoint per LANE here instead of one per wavefront in the descriptor kernels
     dir_sc[(size_t)frame * cap + k] = direction_sincos(kp.angle * (float)(3.1415926535897932384626433832795 / 180));
 }
@@ -2573,13 +2739,17 @@ __global__ __launch_bounds__(1024) void k_classify_scan(int nkeys, int* __restri
 
 __global__ __launch_bounds__(256) void k_classify_scatter(const vo_keypoint* __restrict__ kp_base, int cap,
                                                           const FrameCounters* __restrict__ cnt, int W, int nbins, int nkeys,
-                                                          int* __restrict__ hist, int* __restrict__ lists, size_t list_stride) {
+                                                          int* __restrict__ hist, int* __restrict__ lists, size_t list_stride,
+                                                          int* __restrict__ cls_cnt) {
     const int frame = blockIdx.y;
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= min(cnt[frame].n_raw, cap)) return;
     int cls;
     const int key = classify_key(kp_base[(size_t)frame * cap + k], frame, W, nbins, &cls);
-    lists[cls * list_stride + atomicAdd(&hist[cls * nkeys + key], 1)] = frame * cap + k;
+    if (cls < 4)
+        lists[cls * list_stride + atomicAdd(&hist[cls * nkeys + key], 1)] = frame * cap + k;
+    else
+        lists[4 * list_stride + atomicAdd(&cls_cnt[4], 1)] = frame * cap + k;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2588,6 +2758,7 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const vo_keypoint* __r
 // a2 + a3 of the product path: the two fused Hessian + NMS launches.  dbg_det (inspection only, otherwise null) receives the
 // det planes of frame 0 as the NMS reads them.
 int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_det) {
+    if (ctx->prm.n_octave_layers != kLayersPerOctave - 2) return enqueue_hessian_nms_generic(ctx, fs, describe);
     DetectGeom g;
     g.H = fs.H;
     g.W = fs.W;
@@ -2717,7 +2888,7 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
                                    fs.cls_hist, fs.dir_sc);
                 hipLaunchKernelGGL(k_classify_scan, dim3(4), dim3(1024), 0, ctx->stream, nkeys, fs.cls_hist, fs.cls_cnt);
                 hipLaunchKernelGGL(k_classify_scatter, gk, dim3(256), 0, ctx->stream, fs.kp, fs.cap, fs.cnt, fs.W, nbins, nkeys,
-                                   fs.cls_hist, fs.cls_list, ls);
+                                   fs.cls_hist, fs.cls_list, ls, fs.cls_cnt);
                 if (quads_beside)
                     VO_HIP(hipStreamWaitEvent(ctx->stream, ctx->ev_quads, 0));
                 else
@@ -2755,9 +2926,15 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
             {
                 // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
                 StageScope sc(ctx, ST_DESC_SEQ);
-                hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
-                                   fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
-                                   ctx->prm.upright ? 2 : 1);
+                // (more than three layers per octave: keypoint sizes up to 48 * n_octave_layers + 120, windows up to kHugeWin)
+                if (ctx->prm.n_octave_layers > kLayersPerOctave - 2)
+                    hipLaunchKernelGGL((k_describe<0, kHugeWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                                       fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
+                                       ctx->prm.upright ? 2 : 1);
+                else
+                    hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                                       fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
+                                       ctx->prm.upright ? 2 : 1);
             }
             VO_HIP(hipGetLastError());
         }
