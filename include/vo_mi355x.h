@@ -34,7 +34,7 @@ typedef enum vo_status {
     VO_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 / device index out of range */
     VO_ERR_HIP = -3,           /* a HIP runtime call failed (see vo_last_hip_error)   */
     VO_ERR_CAPACITY = -4,      /* an output did not fit the caller's capacity          */
-    VO_ERR_UNSUPPORTED = -5,   /* parameter combination not implemented (e.g. extended)*/
+    VO_ERR_UNSUPPORTED = -5,   /* parameter value not implemented (e.g. n_octaves > 4) */
     VO_ERR_TOO_FEW_POINTS = -6,/* fewer than 5 correspondences (findEssentialMat fails)*/
     VO_ERR_NO_MODEL = -7       /* RANSAC found no model with more than 4 inliers       */
 } vo_status;
@@ -69,8 +69,11 @@ typedef enum vo_fail { VO_FAIL_DETECTION = 0, VO_NOT_MOVING = 1, VO_FAIL_RECOVER
 typedef struct vo_params {
     float hessian_threshold;      /* minHessian = 50                       :33 */
     int32_t n_octaves;            /* 4 (1..4 accepted)                     :35 */
-    int32_t n_octave_layers;      /* 3 (other values: VO_ERR_UNSUPPORTED)  :36 */
-    int32_t extended;             /* false (64 floats; true: UNSUPPORTED)  :37 */
+    int32_t n_octave_layers;      /* 3 (1..6 accepted; other than 3: plain :36
+                                     det-plane / NMS kernels)                 */
+    int32_t extended;             /* false = 64 floats per descriptor;     :37
+                                     true accepted: 128 floats, sequential
+                                     describer, exact-scan matcher            */
     int32_t upright;              /* false (true accepted: angle 270,      :38
                                      axis-aligned windows, sequential kernel) */
     float ratio_thresh;           /* 0.7f                                  :41 */
@@ -120,7 +123,8 @@ int vo_hessian_product_det(vo_ctx* ctx, const uint8_t* img, int rows, int cols, 
 /* ---- a1-a6: SURF::create(50,4,3,false,false)->detectAndCompute(img, noArray(), kps, desc)
  * camera_utility.hpp:746-750.  kps/desc64 hold up to cap entries; *n = count written.
  * Keypoints come out in OpenCV's KeypointGreater order.  desc64 may be NULL (detect only:
- * angle is then -1 as after fastHessianDetector).                                       */
+ * angle is then -1 as after fastHessianDetector).  A descriptor is 64 floats - 128 when
+ * the context was created with vo_params.extended, here and in vo_match_knn2.           */
 int vo_detect_describe(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step,
                        vo_keypoint* kps, float* desc64, int cap, int* n);
 

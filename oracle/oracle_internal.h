@@ -34,7 +34,7 @@ float fastAtan2(float y, float x);
 void resize_area_u8(const uint8_t* win, int ssize, uint8_t* dst, int dsize);
 void detect_describe(const vo_params& P, const uint8_t* img, int rows, int cols, size_t step,
                      std::vector<vo_keypoint>& kps, std::vector<float>* desc);
-void match_knn2(const float* A, int nA, const float* B, int nB, int32_t* idx2, float* dist2);
+void match_knn2(const float* A, int nA, const float* B, int nB, int32_t* idx2, float* dist2, int dlen = 64);
 int detect_match(const vo_params& P, const uint8_t* img1, size_t step1, const uint8_t* img2, size_t step2, int rows,
                  int cols, std::vector<float>& p1, std::vector<float>& p2, std::vector<vo_dmatch>& m, int* nk1,
                  int* nk2);

@@ -399,7 +399,8 @@ float g_forced_dir = -1.f;
 // window is an axis-aligned pixel rectangle.  That branch is NOT part of SURVEY Appendix A; it restates the published OpenCV source
 // (xfeatures2d surf.cpp, SURFInvoker) and nothing in the reference exercises it: parity unpinned like the rest, one step further.
 static bool describe_one(const InvokerTables& T, const uint8_t* img, size_t imgstep, int rows, int cols,
-                         const int32_t* sum, vo_keypoint& kp, float* vec /*64 or null*/, std::vector<uint8_t>& winbuf, bool upright) {
+                         const int32_t* sum, vo_keypoint& kp, float* vec /*64 (128: extended) or null*/, std::vector<uint8_t>& winbuf, bool upright,
+                         bool extended) {
     const int sw = cols + 1;
     const int sum_rows = rows + 1, sum_cols = cols + 1;
     static const int dx_s[2][5] = {{0, 0, 2, 4, -1}, {2, 0, 4, 4, 1}};
@@ -509,9 +510,37 @@ static bool describe_one(const InvokerTables& T, const uint8_t* img, size_t imgs
             DX[i][j] = vx;
             DY[i][j] = vy;
         }
-    for (int kk = 0; kk < 64; kk++) vec[kk] = 0;
+    const int dlen = extended ? 128 : 64;
+    for (int kk = 0; kk < dlen; kk++) vec[kk] = 0;
     double square_mag = 0;
     float* v = vec;
+    if (extended) {
+        // SURF's `extended` flag (false in the reference, camera_utility.hpp:37): the 128-bin descriptor.  NOT part of SURVEY
+        // Appendix A; restates the published OpenCV source (xfeatures2d surf.cpp, SURFInvoker) - parity unpinned, one step further.
+        for (int i = 0; i < 4; i++)
+            for (int j = 0; j < 4; j++) {
+                for (int y = i * 5; y < i * 5 + 5; y++)
+                    for (int x = j * 5; x < j * 5 + 5; x++) {
+                        float tx = DX[y][x], ty = DY[y][x];
+                        if (ty >= 0) {
+                            v[0] += tx;
+                            v[1] += (float)std::fabs(tx);
+                        } else {
+                            v[2] += tx;
+                            v[3] += (float)std::fabs(tx);
+                        }
+                        if (tx >= 0) {
+                            v[4] += ty;
+                            v[5] += (float)std::fabs(ty);
+                        } else {
+                            v[6] += ty;
+                            v[7] += (float)std::fabs(ty);
+                        }
+                    }
+                for (int kk = 0; kk < 8; kk++) square_mag += v[kk] * v[kk];
+                v += 8;
+            }
+    } else
     for (int i = 0; i < 4; i++)
         for (int j = 0; j < 4; j++) {
             for (int y = i * 5; y < i * 5 + 5; y++)
@@ -526,7 +555,7 @@ static bool describe_one(const InvokerTables& T, const uint8_t* img, size_t imgs
             v += 4;
         }
     float scale = (float)(1. / (std::sqrt(square_mag) + FLT_EPSILON));
-    for (int kk = 0; kk < 64; kk++) vec[kk] *= scale;
+    for (int kk = 0; kk < dlen; kk++) vec[kk] *= scale;
     return true;
 }
 
@@ -539,14 +568,16 @@ void detect_describe(const vo_params& P, const uint8_t* img, int rows, int cols,
     if (!desc) return;
     static const InvokerTables T;
     const int N = (int)kps.size();
-    std::vector<float> d((size_t)N * 64);
+    const int dlen = P.extended ? 128 : 64;
+    std::vector<float> d((size_t)N * dlen);
     std::vector<uint8_t> keep(N, 0);
 #pragma omp parallel
     {
         std::vector<uint8_t> winbuf;
 #pragma omp for schedule(dynamic, 16)
         for (int k = 0; k < N; k++)
-            keep[k] = describe_one(T, img, step, rows, cols, sum.data(), kps[k], d.data() + (size_t)k * 64, winbuf, P.upright != 0);
+            keep[k] = describe_one(T, img, step, rows, cols, sum.data(), kps[k], d.data() + (size_t)k * dlen, winbuf, P.upright != 0,
+                                   P.extended != 0);
     }
     // step 5: drop deleted keypoints preserving order
     int w = 0;
@@ -554,26 +585,26 @@ void detect_describe(const vo_params& P, const uint8_t* img, int rows, int cols,
         if (keep[k]) {
             if (w != k) {
                 kps[w] = kps[k];
-                std::memcpy(d.data() + (size_t)w * 64, d.data() + (size_t)k * 64, 64 * sizeof(float));
+                std::memcpy(d.data() + (size_t)w * dlen, d.data() + (size_t)k * dlen, dlen * sizeof(float));
             }
             w++;
         }
     kps.resize(w);
-    d.resize((size_t)w * 64);
+    d.resize((size_t)w * dlen);
     desc->swap(d);
 }
 
 // ---------------------------------------------------------------- A.7 brute-force 2-NN
-void match_knn2(const float* A, int nA, const float* B, int nB, int32_t* idx2, float* dist2) {
+void match_knn2(const float* A, int nA, const float* B, int nB, int32_t* idx2, float* dist2, int dlen) {
 #pragma omp parallel for schedule(static)
     for (int i = 0; i < nA; i++) {
-        const float* a = A + (size_t)i * 64;
+        const float* a = A + (size_t)i * dlen;
         float d0 = FLT_MAX, d1 = FLT_MAX;
         int i0 = -1, i1 = -1;
         for (int j = 0; j < nB; j++) {
-            const float* b = B + (size_t)j * 64;
+            const float* b = B + (size_t)j * dlen;
             float s = 0;
-            for (int k = 0; k < 64; k++) {
+            for (int k = 0; k < dlen; k++) {
                 float t = a[k] - b[k];
                 s += t * t;
             }
@@ -611,7 +642,7 @@ int detect_match(const vo_params& P, const uint8_t* img1, size_t step1, const ui
     if (k1.empty() || k2.size() < 2) return 0;  // reference: UB when the train set has < 2 rows (:776)
     std::vector<int32_t> idx(2 * k1.size());
     std::vector<float> dist(2 * k1.size());
-    match_knn2(d1.data(), (int)k1.size(), d2.data(), (int)k2.size(), idx.data(), dist.data());
+    match_knn2(d1.data(), (int)k1.size(), d2.data(), (int)k2.size(), idx.data(), dist.data(), P.extended ? 128 : 64);
     for (size_t i = 0; i < k1.size(); i++) {
         bool lowe = dist[2 * i] < P.ratio_thresh * dist[2 * i + 1];
         bool roi = (k1[i].x >= P.roi_x_lo) && (k1[i].x <= P.roi_x_hi) && (k1[i].y >= P.roi_y_lo) &&

@@ -95,6 +95,12 @@ int vo_oracle_match_knn2(const float* descA, int nA, const float* descB, int nB,
     return VO_OK;
 }
 
+int vo_oracle_match_knn2_d(const float* descA, int nA, const float* descB, int nB, int dlen, int32_t* idx2, float* dist2) {
+    if (!descA || !descB || !idx2 || !dist2 || nA < 0 || nB < 0 || dlen < 1) return VO_ERR_INVALID_ARG;
+    match_knn2(descA, nA, descB, nB, idx2, dist2, dlen);
+    return VO_OK;
+}
+
 int vo_oracle_detect_match(const vo_params* p, const uint8_t* img1, size_t step1, const uint8_t* img2, size_t step2,
                            int rows, int cols, float* p1xy, float* p2xy, vo_dmatch* m, int cap, int* n) {
     if (!img1 || !img2 || !n) return VO_ERR_INVALID_ARG;

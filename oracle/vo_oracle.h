@@ -30,6 +30,8 @@ int vo_oracle_debug_force_angle(float degrees); /* test hook: see oracle_surf.cp
 int vo_oracle_detect_describe(const vo_params* p, const uint8_t* img, int rows, int cols, size_t step,
                               vo_keypoint* kps, float* desc64, int cap, int* n);
 int vo_oracle_match_knn2(const float* descA, int nA, const float* descB, int nB, int32_t* idx2, float* dist2);
+/* the same for descriptors of dlen floats (128: SURF's `extended` descriptors) */
+int vo_oracle_match_knn2_d(const float* descA, int nA, const float* descB, int nB, int dlen, int32_t* idx2, float* dist2);
 int vo_oracle_detect_match(const vo_params* p, const uint8_t* img1, size_t step1, const uint8_t* img2,
                            size_t step2, int rows, int cols, float* p1xy, float* p2xy, vo_dmatch* m, int cap,
                            int* n);

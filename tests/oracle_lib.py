@@ -61,7 +61,7 @@ def detect_describe(img, params=None, cap=1 << 17, describe=True):
     img = np.ascontiguousarray(img, np.uint8)
     h, w = img.shape
     kps = np.zeros(cap, KP_DTYPE)
-    desc = np.zeros((cap, 64), np.float32) if describe else None
+    desc = np.zeros((cap, 128 if (params is not None and params.extended) else 64), np.float32) if describe else None
     n = C.c_int(0)
     _chk(lib.vo_oracle_detect_describe(C.byref(params) if params else None, _p(img, u8p), h, w, C.c_size_t(img.strides[0]),
                                        kps.ctypes.data_as(C.c_void_p), _p(desc, f32p) if describe else None, cap, C.byref(n)))
@@ -73,7 +73,10 @@ def match_knn2(a, b):
     b = np.ascontiguousarray(b, np.float32)
     idx = np.zeros((len(a), 2), np.int32)
     dist = np.zeros((len(a), 2), np.float32)
-    _chk(lib.vo_oracle_match_knn2(_p(a, f32p), len(a), _p(b, f32p), len(b), _p(idx, i32p), _p(dist, f32p)))
+    if a.shape[1] == 64:
+        _chk(lib.vo_oracle_match_knn2(_p(a, f32p), len(a), _p(b, f32p), len(b), _p(idx, i32p), _p(dist, f32p)))
+    else:
+        _chk(lib.vo_oracle_match_knn2_d(_p(a, f32p), len(a), _p(b, f32p), len(b), a.shape[1], _p(idx, i32p), _p(dist, f32p)))
     return idx, dist
 
 

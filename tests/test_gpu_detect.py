@@ -390,10 +390,46 @@ def test_octave_layer_variants(ctx, n_layers, n_oct, upright):
         c.close()
 
 
+@pytest.mark.parametrize("n_layers,upright", [(3, 0), (3, 1), (4, 0)])
+def test_extended_descriptors(ctx, n_layers, upright):
+    """vo_params.extended (camera_utility.hpp:37 is a mutable global; the reference leaves it false): 128 floats per keypoint, the
+    sums of every cell kept apart by the sign of the other gradient.  Bit-exact against the oracle's restatement of the published
+    OpenCV loop (outside SURVEY Appendix A: parity unpinned); independent of the oracle: the keypoints are those of the 64-float
+    run, every vector has unit length, and folding the sign classes back together gives the 64-float vector's direction."""
+    from visual_odometry_amd.frontend import Context, default_params
+
+    p = default_params()
+    p.extended, p.n_octave_layers, p.upright = 1, n_layers, upright
+    p64 = default_params()
+    p64.n_octave_layers, p64.upright = n_layers, upright
+    c, c64 = Context(p), Context(p64)
+    try:
+        assert c.descriptor_length == 128
+        for img in (_scene(480, 640, 700, 1001).img1, _scene(243, 322, 150, 11).img1, _wide_blob_frame(600, 800, 70, 5, 4.0, 32.0)):
+            k, d = c.detect_describe(img)
+            rk, rd = O.detect_describe(img, params=p)
+            assert d.shape == (len(k), 128) and rd.shape == d.shape
+            _assert_kps_equal(k, rk)
+            bad = np.flatnonzero((d.view(np.uint32) != rd.view(np.uint32)).any(axis=1))
+            assert len(bad) == 0, (len(bad), len(k), bad[:10])
+            k6, d6 = c64.detect_describe(img)
+            _assert_kps_equal(k, k6)
+            assert np.allclose(np.linalg.norm(d.astype(np.float64), axis=1), 1.0, atol=1e-6)
+            e = d.astype(np.float64).reshape(len(k), 16, 8)
+            fold = np.stack([e[:, :, 0] + e[:, :, 2], e[:, :, 4] + e[:, :, 6], e[:, :, 1] + e[:, :, 3], e[:, :, 5] + e[:, :, 7]], axis=2)
+            fold = fold.reshape(len(k), 64)
+            d6 = d6.astype(np.float64)
+            cosine = (fold * d6).sum(axis=1) / (np.linalg.norm(fold, axis=1) * np.linalg.norm(d6, axis=1))
+            assert cosine.min() > 1 - 1e-9, cosine.min()
+    finally:
+        c.close()
+        c64.close()
+
+
 def test_unsupported_surf_variants_are_refused():
     from visual_odometry_amd.frontend import Context, VoError, default_params
 
-    for field, value in (("n_octave_layers", 0), ("n_octave_layers", 7), ("extended", 1), ("n_octaves", 5), ("n_octaves", 0)):
+    for field, value in (("n_octave_layers", 0), ("n_octave_layers", 7), ("n_octaves", 5), ("n_octaves", 0)):
         p = default_params()
         setattr(p, field, value)
         with pytest.raises(VoError):

@@ -198,13 +198,45 @@ def test_opt_detect_features_parity(ctx, shape, nb, seed):
     assert kP.Kpoints1[:, 1].min() >= 20 and kP.Kpoints1[:, 1].max() <= 482
 
 
-@pytest.mark.parametrize("n_oct,upright", [(2, 0), (4, 1)])
-def test_opt_detect_features_parity_with_surf_variants(n_oct, upright):
-    """The whole opt_DetectFeatures with fewer octaves / upright descriptors (vo_params.n_octaves, .upright) against the oracle."""
+@pytest.mark.parametrize("na,nb,seed", [(1000, 1200, 1), (1, 2, 3), (333, 31, 4), (2500, 3000, 5), (70, 1, 6), (257, 33, 7)])
+def test_knn2_of_128_float_descriptors(na, nb, seed):
+    """The matcher of an `extended` context (k_match_scan: exact scan, no shortlist): indices and distance bits equal the
+    oracle's, ties to the lower train index, and the 2-NN equal numpy's in double precision."""
     from visual_odometry_amd.frontend import Context, default_params
 
     p = default_params()
-    p.n_octaves, p.upright = n_oct, upright
+    p.extended = 1
+    c = Context(p)
+    try:
+        rng = np.random.default_rng(seed)
+        a = np.concatenate([synth.surf_like_descriptors(na, seed), synth.surf_like_descriptors(na, seed + 50)], axis=1) * np.float32(0.70710678)
+        b = np.concatenate([synth.surf_like_descriptors(nb, seed + 100), synth.surf_like_descriptors(nb, seed + 150)], axis=1) * np.float32(0.70710678)
+        k = min(na, nb) // 3
+        b[:k] = a[:k] + rng.normal(0, 1e-3, size=(k, 128)).astype(np.float32)
+        if nb >= 20:
+            b[nb - 5 : nb] = b[:5]  # exact duplicates: ties
+        idx, dist = c.match_knn2(a, b)
+        ridx, rdist = O.match_knn2(a, b)
+        assert np.array_equal(idx, ridx)
+        assert np.array_equal(dist.view(np.uint32), rdist.view(np.uint32))
+        if nb >= 2:
+            d2 = ((a[:, None, :].astype(np.float64) - b[None, :, :].astype(np.float64)) ** 2).sum(-1)
+            best = np.sort(d2, axis=1)[:, :2]
+            assert np.allclose(dist.astype(np.float64) ** 2, best, rtol=1e-5, atol=1e-9)
+        with pytest.raises(ValueError):
+            c.match_knn2(a[:, :64], b[:, :64])
+    finally:
+        c.close()
+
+
+@pytest.mark.parametrize("n_oct,upright,n_layers,extended", [(2, 0, 3, 0), (4, 1, 3, 0), (4, 0, 4, 0), (4, 0, 3, 1), (3, 0, 2, 1)])
+def test_opt_detect_features_parity_with_surf_variants(n_oct, upright, n_layers, extended):
+    """The whole opt_DetectFeatures with fewer octaves / upright descriptors / other layer counts / 128-float descriptors
+    (vo_params.n_octaves, .upright, .n_octave_layers, .extended) against the oracle."""
+    from visual_odometry_amd.frontend import Context, default_params
+
+    p = default_params()
+    p.n_octaves, p.upright, p.n_octave_layers, p.extended = n_oct, upright, n_layers, extended
     c = Context(p)
     try:
         sc = synth.blob_scene(480, 640, synth.K_PARETE, 700, 1001)

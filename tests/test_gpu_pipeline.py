@@ -776,15 +776,16 @@ def test_pair_batch_from_python_matches_the_batch_api(ctx):
         e.close()
 
 
-@pytest.mark.parametrize("n_oct,n_layers,upright", [(3, 3, 1), (4, 4, 0), (4, 2, 0)])
-def test_batch_with_surf_variants_equals_the_single_calls_and_the_oracle(n_oct, n_layers, upright):
+@pytest.mark.parametrize("n_oct,n_layers,upright,extended", [(3, 3, 1, 0), (4, 4, 0, 0), (4, 2, 0, 0), (4, 3, 0, 1)])
+def test_batch_with_surf_variants_equals_the_single_calls_and_the_oracle(n_oct, n_layers, upright, extended):
     """vo_params.n_octaves = 3 and upright through the batch path (the octave-1 launch stays, octave 3's tiles are gone, every
     keypoint is described by the sequential kernel), and layer counts other than 3 (the plain det-plane / NMS kernels in place of
-    the two fused launches, all frames of the batch in one group): records and matches equal the synchronous calls and the oracle."""
+    the two fused launches, all frames of the batch in one group), and 128-float descriptors (sequential describer, exact-scan
+    matcher): records and matches equal the synchronous calls and the oracle."""
     from visual_odometry_amd.frontend import Context, default_params
 
     p = default_params()
-    p.n_octaves, p.n_octave_layers, p.upright = n_oct, n_layers, upright
+    p.n_octaves, p.n_octave_layers, p.upright, p.extended = n_oct, n_layers, upright, extended
     c = Context(p)
     try:
         scenes = [synth.blob_scene(480, 640, synth.K_PARETE, nb, seed) for nb, seed in [(700, 21), (400, 22), (900, 23)]]

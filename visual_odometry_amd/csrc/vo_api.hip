@@ -141,9 +141,10 @@ static void dfree(T*& p) {
     p = nullptr;
 }
 
-int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
-    if (fs.F == F && fs.H == H && fs.W == W && fs.cap == cap && fs.img) return VO_OK;
+int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap, int dlen) {
+    if (fs.F == F && fs.H == H && fs.W == W && fs.cap == cap && fs.dlen == dlen && fs.img) return VO_OK;
     vo_frameset_free(fs);
+    fs.dlen = dlen;
     fs.F = F;
     fs.H = H;
     fs.W = W;
@@ -157,7 +158,7 @@ int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap) {
     VO_TRY(dalloc(fs.kp_raw, (size_t)F * cap));
     VO_TRY(dalloc(fs.kp, (size_t)F * cap));
     VO_TRY(dalloc(fs.rank, (size_t)F * cap));
-    VO_TRY(dalloc(fs.desc, (size_t)F * cap * 64));
+    VO_TRY(dalloc(fs.desc, (size_t)F * cap * dlen));
     VO_TRY(dalloc(fs.descT, (size_t)F * cap * 72));  // 9 slabs of 32 B per row
     VO_TRY(dalloc(fs.nrm, (size_t)F * cap));
     VO_TRY(dalloc(fs.nmax, (size_t)F));
@@ -220,9 +221,11 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         p = *params;
     else
         vo_params_default(&p);
-    // supported: the reference's values (4, 3, false, false); fewer octaves; upright.  Not: other layer counts, 128-float descriptors
-    if (p.n_octaves < 1 || p.n_octaves > 4 || p.n_octave_layers < 1 || p.n_octave_layers > kMaxOctaveLayers || p.extended) return VO_ERR_UNSUPPORTED;
+    // the reference's values (4, 3, false, false) take the tuned kernels; fewer octaves, 1..6 layers per octave, upright and
+    // extended (128-float descriptors) take plain forms of the same arithmetic
+    if (p.n_octaves < 1 || p.n_octaves > 4 || p.n_octave_layers < 1 || p.n_octave_layers > kMaxOctaveLayers) return VO_ERR_UNSUPPORTED;
     p.upright = p.upright ? 1 : 0;
+    p.extended = p.extended ? 1 : 0;
     if (p.kp_capacity < 64 || p.match_capacity < 8 || p.ransac_max_iters < 1 || p.ransac_max_iters > kMaxHyp)
         return VO_ERR_INVALID_ARG;
     p.kp_capacity = (p.kp_capacity + 63) & ~63;
@@ -400,7 +403,7 @@ extern "C" int vo_integral(vo_ctx* ctx, const uint8_t* img, int rows, int cols, 
     if (!ctx || !sum) return VO_ERR_INVALID_ARG;
     VO_TRY(check_image(img, rows, cols, step));
     VO_HIP(hipSetDevice(ctx->device));
-    VO_TRY(vo_frameset_alloc(ctx->fs, 1, rows, cols, ctx->prm.kp_capacity));
+    VO_TRY(vo_frameset_alloc(ctx->fs, 1, rows, cols, ctx->prm.kp_capacity, vo_desc_len(ctx)));
     VO_TRY(upload_frame(ctx, ctx->fs, 0, img, step));
     VO_TRY(vo_enqueue_integral(ctx, ctx->fs, ctx->stream));
     VO_HIP(hipMemcpyAsync(sum, ctx->fs.sum, ctx->fs.sum_stride() * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -414,7 +417,7 @@ extern "C" int vo_hessian_layer(vo_ctx* ctx, const uint8_t* img, int rows, int c
         return VO_ERR_INVALID_ARG;
     VO_TRY(check_image(img, rows, cols, step));
     VO_HIP(hipSetDevice(ctx->device));
-    VO_TRY(vo_frameset_alloc(ctx->fs, 1, rows, cols, ctx->prm.kp_capacity));
+    VO_TRY(vo_frameset_alloc(ctx->fs, 1, rows, cols, ctx->prm.kp_capacity, vo_desc_len(ctx)));
     VO_TRY(upload_frame(ctx, ctx->fs, 0, img, step));
     VO_TRY(vo_enqueue_integral(ctx, ctx->fs, ctx->stream));
     const size_t n = (size_t)(rows >> octave) * (cols >> octave);
@@ -440,7 +443,7 @@ extern "C" int vo_hessian_product_det(vo_ctx* ctx, const uint8_t* img, int rows,
     if (n_floats != S) return VO_ERR_INVALID_ARG;
     VO_HIP(hipSetDevice(ctx->device));
     FrameSet& fs = ctx->fs;
-    VO_TRY(vo_frameset_alloc(fs, 1, rows, cols, ctx->prm.kp_capacity));
+    VO_TRY(vo_frameset_alloc(fs, 1, rows, cols, ctx->prm.kp_capacity, vo_desc_len(ctx)));
     VO_TRY(reset_counters(ctx, fs));
     VO_TRY(upload_frame(ctx, fs, 0, img, step));
     VO_TRY(vo_enqueue_integral(ctx, fs, ctx->stream));
@@ -461,7 +464,7 @@ extern "C" int vo_detect_describe(vo_ctx* ctx, const uint8_t* img, int rows, int
     VO_TRY(check_image(img, rows, cols, step));
     VO_HIP(hipSetDevice(ctx->device));
     FrameSet& fs = ctx->fs;
-    VO_TRY(vo_frameset_alloc(fs, 1, rows, cols, ctx->prm.kp_capacity));
+    VO_TRY(vo_frameset_alloc(fs, 1, rows, cols, ctx->prm.kp_capacity, vo_desc_len(ctx)));
     VO_TRY(reset_counters(ctx, fs));
     VO_TRY(upload_frame(ctx, fs, 0, img, step));
     VO_TRY(vo_enqueue_detect(ctx, fs, desc64 != nullptr));
@@ -476,9 +479,9 @@ extern "C" int vo_detect_describe(vo_ctx* ctx, const uint8_t* img, int rows, int
     if (c.n_raw > fs.cap || c.n_raw > cap) return VO_ERR_CAPACITY;
     if (c.n_raw > 0) {
         BounceDown dn;
-        VO_TRY(dn.begin(ctx, (size_t)c.n_raw * (sizeof(vo_keypoint) + 64 * sizeof(float))));
+        VO_TRY(dn.begin(ctx, (size_t)c.n_raw * (sizeof(vo_keypoint) + fs.dlen * sizeof(float))));
         VO_TRY(dn.add(kps, fs.kp, (size_t)c.n_raw * sizeof(vo_keypoint)));
-        if (desc64) VO_TRY(dn.add(desc64, fs.desc, (size_t)c.n_raw * 64 * sizeof(float)));
+        if (desc64) VO_TRY(dn.add(desc64, fs.desc, (size_t)c.n_raw * fs.dlen * sizeof(float)));
         VO_TRY(dn.finish());
     }
     return VO_OK;
@@ -614,18 +617,18 @@ extern "C" int vo_match_knn2(vo_ctx* ctx, const float* descA, int nA, const floa
     VO_HIP(hipSetDevice(ctx->device));
     const int cap = round_up(std::max(std::max(nA, nB), 64), 64);
     FrameSet& fs = ctx->fs;
-    VO_TRY(vo_frameset_alloc(fs, 2, 16, 16, cap));
+    VO_TRY(vo_frameset_alloc(fs, 2, 16, 16, cap, vo_desc_len(ctx)));
     VO_TRY(ctx_pairset(ctx, cap, 64));
     FrameCounters c[2];
     std::memset(c, 0, sizeof(c));
     c[0].n_raw = c[0].n_kp = nA;
     c[1].n_raw = c[1].n_kp = nB;
-    const size_t bA = (size_t)nA * 64 * sizeof(float), bB = (size_t)nB * 64 * sizeof(float);
+    const size_t bA = (size_t)nA * fs.dlen * sizeof(float), bB = (size_t)nB * fs.dlen * sizeof(float);
     uint8_t* up = nullptr;
     VO_TRY(ctx_bounce(ctx, 64 + bA + bB, false, &up));
     VO_TRY(bounce_up(ctx, up, 0, fs.cnt, c, sizeof(c)));
     VO_TRY(bounce_up(ctx, up, 64, fs.desc, descA, bA));
-    VO_TRY(bounce_up(ctx, up, 64 + bA, fs.desc + (size_t)cap * 64, descB, bB));
+    VO_TRY(bounce_up(ctx, up, 64 + bA, fs.desc + (size_t)cap * fs.dlen, descB, bB));
     VO_TRY(vo_enqueue_match(ctx, fs, ctx->ps, false, ctx->stream));
     BounceDown dn;
     VO_TRY(dn.begin(ctx, (size_t)nA * 2 * (sizeof(int) + sizeof(float))));
@@ -644,7 +647,7 @@ extern "C" int vo_detect_match(vo_ctx* ctx, const uint8_t* img1, size_t step1, c
     VO_HIP(hipSetDevice(ctx->device));
     FrameSet& fs = ctx->fs;
     PairSet& ps = ctx->ps;
-    VO_TRY(vo_frameset_alloc(fs, 2, rows, cols, ctx->prm.kp_capacity));
+    VO_TRY(vo_frameset_alloc(fs, 2, rows, cols, ctx->prm.kp_capacity, vo_desc_len(ctx)));
     VO_TRY(ctx_pairset(ctx, ctx->prm.kp_capacity, round_up(ctx->prm.match_capacity, 64)));
     VO_TRY(reset_counters(ctx, fs));
     VO_TRY(upload_frame(ctx, fs, 0, img1, step1));
@@ -896,7 +899,7 @@ static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq
     b->is_seq = is_seq;
     b->rows = rows;
     b->cols = cols;
-    int st = vo_frameset_alloc(b->fs, n_frames, rows, cols, ctx->prm.kp_capacity);
+    int st = vo_frameset_alloc(b->fs, n_frames, rows, cols, ctx->prm.kp_capacity, vo_desc_len(ctx));
     if (st == VO_OK) st = vo_pairset_alloc(b->ps, n_pairs, ctx->prm.kp_capacity, round_up(ctx->prm.match_capacity, 64), kMaxHyp);
     if (st != VO_OK) {
         vo_batch_destroy(b);
@@ -912,7 +915,7 @@ static int batch_create_impl(vo_ctx* ctx, int n_frames, int n_pairs, bool is_seq
         const size_t fc = (size_t)n_frames * fs.cap;
         b->feat[0] = FeatBuf{fs.kp, fs.desc, fs.descT, fs.nrm, fs.nmax, fs.cnt};
         FeatBuf& x = b->feat[1];
-        ok = ok && dalloc(x.kp, fc) == VO_OK && dalloc(x.desc, fc * 64) == VO_OK && dalloc(x.descT, fc * 72) == VO_OK &&
+        ok = ok && dalloc(x.kp, fc) == VO_OK && dalloc(x.desc, fc * fs.dlen) == VO_OK && dalloc(x.descT, fc * 72) == VO_OK &&
              dalloc(x.nrm, fc) == VO_OK && dalloc(x.nmax, (size_t)n_frames) == VO_OK && dalloc(x.cnt, (size_t)n_frames) == VO_OK &&
              hipMemset(x.cnt, 0, (size_t)n_frames * sizeof(FrameCounters)) == hipSuccess;
     }

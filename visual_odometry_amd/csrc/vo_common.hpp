@@ -133,6 +133,7 @@ constexpr int kClsCntInts = kTicketBase + 5 * 8 * kTicketStride;
 
 struct FrameSet {
     int F = 0, H = 0, W = 0, cap = 0;
+    int dlen = 64;               // floats per descriptor: 64, or 128 with vo_params.extended
     uint8_t* img = nullptr;      // [F][H][W]
     int32_t* sum = nullptr;      // [F][H+1][W+1]
     int32_t* sum4 = nullptr;     // [F][4][H+1][sum4_pitch] the same values by column phase: sum[y][x] at plane x & 3, word x >> 2 (coarse octaves)
@@ -141,7 +142,7 @@ struct FrameSet {
     vo_keypoint* kp_raw = nullptr;  // [F][cap]
     vo_keypoint* kp = nullptr;      // [F][cap] sorted
     int* rank = nullptr;            // [F][cap]
-    float* desc = nullptr;          // [F][cap][64]
+    float* desc = nullptr;          // [F][cap][dlen]
     float* descT = nullptr;         // [F][cap/32][9][64] x 16 B: MFMA operand layout (bf16 high parts, low parts, norm term)
     float* nrm = nullptr;           // [F][cap]  -0.5*||b||^2
     int* nmax = nullptr;            // [F] bits of the largest ||b||^2 of the frame
@@ -297,7 +298,8 @@ struct vo_batch {
 };
 
 // ---------------------------------------------------------------- helpers (vo_api.cpp)
-int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap);
+int vo_frameset_alloc(FrameSet& fs, int F, int H, int W, int cap, int dlen = 64);
+inline int vo_desc_len(const vo_ctx* ctx) { return ctx->prm.extended ? 128 : 64; }
 void vo_frameset_free(FrameSet& fs);
 int vo_pairset_alloc(PairSet& ps, int P, int kp_cap, int match_cap, int max_hyp);
 void vo_pairset_free(PairSet& ps);

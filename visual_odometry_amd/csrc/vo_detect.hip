@@ -1639,20 +1639,66 @@ __device__ __forceinline__ void describe_patch_to_vec(int tid, int NT, const uin
     }
 }
 
+// The 128-float form of the same step (SURF's `extended` flag; false in the reference, camera_utility.hpp:37; not part of SURVEY
+// Appendix A - restated from the published OpenCV source, parity unpinned like `upright`): per cell the sums of dx and |dx| are
+// kept apart by the sign of dy (dy >= 0 first), those of dy and |dy| by the sign of dx.  Thread = cell * 8 + q (needs NT >= 128);
+// a term of the other sign is skipped, as in the reference's branches.  square_mag is the reference's sequential double sum.
+// s_vec holds 128 floats.
+__device__ __forceinline__ void describe_patch_to_vec_ext(int tid, int NT, const uint8_t* s_patch, float* s_grad, float* s_vec,
+                                                          float* __restrict__ desc_out) {
+    float* s_DX = s_grad;
+    float* s_DY = s_grad + kPatch * kPatch;
+    for (int it = tid; it < kPatch * kPatch; it += NT) {
+        const int i = it / kPatch, j = it - i * kPatch;
+        const float dw = c_tab.DW[it];
+        const int p00 = s_patch[i * (kPatch + 1) + j], p01 = s_patch[i * (kPatch + 1) + j + 1];
+        const int p10 = s_patch[(i + 1) * (kPatch + 1) + j], p11 = s_patch[(i + 1) * (kPatch + 1) + j + 1];
+        s_DX[it] = (float)(p01 - p00 + p11 - p10) * dw;
+        s_DY[it] = (float)(p10 - p00 + p11 - p01) * dw;
+    }
+    __syncthreads();
+    float acc = 0.f;
+    if (tid < 128) {
+        const int cell = tid >> 3, q = tid & 7;
+        const int ci = cell >> 2, cj = cell & 3;
+        const float* val = (q & 4) ? s_DY : s_DX;    // what is summed
+        const float* cond = (q & 4) ? s_DX : s_DY;   // whose sign selects
+        const bool want_nonneg = (q & 2) == 0, absolute = (q & 1) != 0;
+        for (int y = 0; y < 5; y++)
+            for (int x = 0; x < 5; x++) {
+                const int o = (ci * 5 + y) * kPatch + cj * 5 + x;
+                const float v = val[o];
+                if ((cond[o] >= 0.f) == want_nonneg) acc += absolute ? fabsf(v) : v;
+            }
+        s_vec[tid] = acc;
+    }
+    __syncthreads();
+    if (tid < 128) {
+        double square_mag = 0;
+        for (int kk = 0; kk < 128; kk++) {
+            const float v = s_vec[kk];
+            square_mag += (double)(v * v);
+        }
+        const float nscale = (float)(1. / (sqrt(square_mag) + (double)FLT_EPSILON));
+        desc_out[tid] = acc * nscale;
+    }
+}
+
 // The reference's own walk, kept as the fallback for keypoints whose window coordinates are not exact in closed form
 // (see k_describe_tiled): correctness over speed.  NT threads cooperate on one keypoint of list `cls`.
 template <int WLO, int WHI, int NT>
 __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img_base, size_t img_stride,
                                                  const int32_t* __restrict__ sum_base, size_t sum_stride, int H, int W,
                                                  vo_keypoint* __restrict__ kp_base, float* __restrict__ desc_base,
-                                                 int cap, const int* __restrict__ list, int* __restrict__ cls_cnt, int cls, int have_dir) {
+                                                 int cap, const int* __restrict__ list, int* __restrict__ cls_cnt, int cls, int have_dir,
+                                                 int extended) {
     __shared__ float2 s_XY[kOriSamples + 15];
     __shared__ int s_A[kOriSamples + 15];
     __shared__ CellTab s_cell[kPatch + 1];
     __shared__ PixTab s_pix[WHI];
     __shared__ float s_rowbuf[(WHI < 40 ? 40 : WHI) * (kPatch + 1)];  // float or int row accumulators; later DX/DY
     __shared__ uint8_t s_patch[(kPatch + 1) * (kPatch + 1) + 7];
-    __shared__ float s_vec[64];
+    __shared__ float s_vec[128];
     __shared__ float s_dir;
     __shared__ int s_item;
 
@@ -1660,6 +1706,7 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     const int lane = tid & 63;
     const int sw = W + 1;
     const int n_items = cls_cnt[cls];
+    static_assert(NT >= 128, "describe_patch_to_vec_ext");
     // work queue: keypoints of this window class, handed out one per workgroup by an atomic ticket; every
     // workgroup leaves as soon as its ticket is past the end of the list
     for (;;) {
@@ -1783,7 +1830,10 @@ __global__ __launch_bounds__(NT) void k_describe(const uint8_t* __restrict__ img
     }
     __syncthreads();
 
-    describe_patch_to_vec(tid, NT, s_patch, s_rowbuf, s_vec, desc_base + ((size_t)frame * cap + k) * 64);
+    if (extended)
+        describe_patch_to_vec_ext(tid, NT, s_patch, s_rowbuf, s_vec, desc_base + ((size_t)frame * cap + k) * 128);
+    else
+        describe_patch_to_vec(tid, NT, s_patch, s_rowbuf, s_vec, desc_base + ((size_t)frame * cap + k) * 64);
     }  // work queue
 }
 
@@ -2896,7 +2946,8 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
             }
             // upright windows are pixel rectangles: every keypoint takes the sequential kernel, which has that branch (the flag is off
             // in the reference, camera_utility.hpp:38: correctness only, no tiled form)
-            const int force_seq = (ctx->force_seq_describe || ctx->prm.upright) ? 1 : 0;
+            // (likewise the 128-float descriptors of `extended`, :37: the sequential kernel has that form of the last step)
+            const int force_seq = (ctx->force_seq_describe || ctx->prm.upright || ctx->prm.extended) ? 1 : 0;
 #define LAUNCH_TILED(STAGE, HI, NW, RB, UMAX, G, CH, CLS, GRID, STREAM)                                                             \
     {                                                                                                                              \
         StageScope sc(ctx, STAGE);                                                                                                 \
@@ -2930,11 +2981,11 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
                 if (ctx->prm.n_octave_layers > kLayersPerOctave - 2)
                     hipLaunchKernelGGL((k_describe<0, kHugeWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                                        fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
-                                       ctx->prm.upright ? 2 : 1);
+                                       ctx->prm.upright ? 2 : 1, ctx->prm.extended);
                 else
                     hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                                        fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
-                                       ctx->prm.upright ? 2 : 1);
+                                       ctx->prm.upright ? 2 : 1, ctx->prm.extended);
             }
             VO_HIP(hipGetLastError());
         }

@@ -585,6 +585,63 @@ __global__ __launch_bounds__(256) void k_match_exact(const float* __restrict__ d
     }
 }
 
+// Exact 2-NN of EVERY query, any descriptor length: the matcher of the 128-float (`extended`) descriptors, which the reference
+// switches off (camera_utility.hpp:37) and the MFMA shortlist above - built for 64 floats - does not serve.  One query per
+// thread with its descriptor in registers, train rows staged in LDS 32 at a time and read as broadcasts, distances summed
+// in the oracle's order (A.7), rows visited in ascending order with strict '<': ties keep the lower train index.
+template <int D>
+__global__ __launch_bounds__(256) void k_match_scan(const float* __restrict__ desc_base, const FrameCounters* __restrict__ cnt, int cap,
+                                                    const int2* __restrict__ pair_frames, int* __restrict__ knn_idx,
+                                                    float* __restrict__ knn_dist) {
+    constexpr int TR = 32;
+    __shared__ float4 s_b[TR * D / 4];
+    const int pair = blockIdx.y, tid = threadIdx.x;
+    const int fa = pair_frames[pair].x, fb = pair_frames[pair].y;
+    const int nA = min(cnt[fa].n_raw, cap), nB = min(cnt[fb].n_raw, cap);
+    if ((int)blockIdx.x * 256 >= nA) return;
+    const int q = blockIdx.x * 256 + tid;
+    float a[D];
+    {
+        const float4* ap = reinterpret_cast<const float4*>(desc_base + ((size_t)fa * cap + min(q, nA - 1)) * D);
+#pragma unroll
+        for (int k4 = 0; k4 < D / 4; k4++) {
+            const float4 v = ap[k4];
+            a[4 * k4] = v.x, a[4 * k4 + 1] = v.y, a[4 * k4 + 2] = v.z, a[4 * k4 + 3] = v.w;
+        }
+    }
+    float d0 = FLT_MAX, d1 = FLT_MAX;
+    int i0 = 0x7fffffff, i1 = 0x7fffffff;
+    const float4* bsrc = reinterpret_cast<const float4*>(desc_base + (size_t)fb * cap * D);
+    for (int r0 = 0; r0 < nB; r0 += TR) {
+        const int nr = min(TR, nB - r0);
+        __syncthreads();
+        for (int e = tid; e < nr * (D / 4); e += 256) s_b[e] = bsrc[(size_t)r0 * (D / 4) + e];
+        __syncthreads();
+        for (int r = 0; r < nr; r++) {
+            float sacc = 0.f;
+#pragma unroll
+            for (int k4 = 0; k4 < D / 4; k4++) {
+                const float4 v = s_b[r * (D / 4) + k4];
+                float t = a[4 * k4] - v.x;
+                sacc += t * t;
+                t = a[4 * k4 + 1] - v.y;
+                sacc += t * t;
+                t = a[4 * k4 + 2] - v.z;
+                sacc += t * t;
+                t = a[4 * k4 + 3] - v.w;
+                sacc += t * t;
+            }
+            if (sacc < d0) {
+                d1 = d0, i1 = i0;
+                d0 = sacc, i0 = r0 + r;
+            } else if (sacc < d1) {
+                d1 = sacc, i1 = r0 + r;
+            }
+        }
+    }
+    if (q < nA) knn_store(knn_idx, knn_dist, ((size_t)pair * cap + q) * 2, d0, i0, d1, i1);
+}
+
 // ------------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(1024) void k_match_filter(const vo_keypoint* __restrict__ kp_base,
                                                        const FrameCounters* __restrict__ cnt, int cap,
@@ -657,9 +714,32 @@ __global__ __launch_bounds__(1024) void k_match_filter(const vo_keypoint* __rest
 }
 
 // ------------------------------------------------------------------------------------------------
+static int enqueue_filter(vo_ctx* ctx, FrameSet& fs, PairSet& ps, hipStream_t stream) {
+    const vo_params& p = ctx->prm;
+    hipLaunchKernelGGL(k_match_filter, dim3(ps.P), dim3(1024), 0, stream, fs.kp, fs.cnt, fs.cap, ps.frames, ps.knn_idx, ps.knn_dist,
+                       p.ratio_thresh, p.roi_x_lo, p.roi_y_lo, p.roi_x_hi, p.roi_y_hi, ps.match_cap, ps.p1, ps.p2, ps.matches, ps.st);
+    VO_HIP(hipGetLastError());
+    return VO_OK;
+}
+
 int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter, hipStream_t stream) {
     ctx->d_redo_cnt = ps.redo_cnt;
     const int cap = fs.cap, P = ps.P;
+    if (fs.dlen != 64) {
+        // 128-float descriptors: the plain exact scan (see k_match_scan), timed as the shortlist stage
+        {
+            StageScope sc(ctx, ST_MATCH_MFMA, stream);
+            VO_HIP(hipMemsetAsync(ps.redo_cnt, 0, sizeof(int), stream));
+            hipLaunchKernelGGL(k_match_scan<128>, dim3((cap + 255) / 256, P), dim3(256), 0, stream, fs.desc, fs.cnt, cap, ps.frames,
+                               ps.knn_idx, ps.knn_dist);
+            VO_HIP(hipGetLastError());
+        }
+        if (filter) {
+            StageScope sc(ctx, ST_MATCH_SELECT, stream);
+            VO_TRY(enqueue_filter(ctx, fs, ps, stream));
+        }
+        return VO_OK;
+    }
     {
         StageScope sc(ctx, ST_MATCH_PREP, stream);
         VO_HIP(hipMemsetAsync(fs.nmax, 0, (size_t)fs.F * sizeof(int), stream));
@@ -689,13 +769,8 @@ int vo_enqueue_match(vo_ctx* ctx, FrameSet& fs, PairSet& ps, bool filter, hipStr
                            ps.cand_val, fs.nmax, 2 * ksplit, cert_scale, ps.knn_idx, ps.knn_dist, ps.redo_list, ps.redo_cnt);
         hipLaunchKernelGGL(k_match_exact, dim3(1024), dim3(256), 0, stream, fs.desc, fs.cnt, cap, ps.frames, ps.redo_list,
                            ps.redo_cnt, ps.knn_idx, ps.knn_dist);
-        if (filter) {
-            const vo_params& p = ctx->prm;
-            hipLaunchKernelGGL(k_match_filter, dim3(P), dim3(1024), 0, stream, fs.kp, fs.cnt, cap, ps.frames,
-                               ps.knn_idx, ps.knn_dist, p.ratio_thresh, p.roi_x_lo, p.roi_y_lo, p.roi_x_hi, p.roi_y_hi, ps.match_cap,
-                               ps.p1, ps.p2, ps.matches, ps.st);
-        }
         VO_HIP(hipGetLastError());
+        if (filter) VO_TRY(enqueue_filter(ctx, fs, ps, stream));
     }
     return VO_OK;
 }

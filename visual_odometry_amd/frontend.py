@@ -140,16 +140,23 @@ class Context:
         h, w = img.shape
         cap = cap or self.params.kp_capacity
         kps = np.zeros(cap, KP_DTYPE)
-        desc = np.zeros((cap, 64), np.float32) if describe else None
+        desc = np.zeros((cap, self.descriptor_length), np.float32) if describe else None
         n = C.c_int(0)
         self._chk(self.lib.vo_detect_describe(self._h, _p(img, u8p), h, w, C.c_size_t(img.strides[0]), kps.ctypes.data_as(C.c_void_p),
                                               _p(desc, f32p) if describe else None, cap, C.byref(n)))
         return kps[: n.value].copy(), (desc[: n.value].copy() if describe else None)
 
+    @property
+    def descriptor_length(self) -> int:
+        """64 floats, or 128 with vo_params.extended (SURF's `extended`, camera_utility.hpp:37)"""
+        return 128 if self.params.extended else 64
+
     # ---- a7
     def match_knn2(self, a, b):
         a = np.ascontiguousarray(a, np.float32)
         b = np.ascontiguousarray(b, np.float32)
+        if a.ndim != 2 or b.ndim != 2 or a.shape[1] != self.descriptor_length or b.shape[1] != self.descriptor_length:
+            raise ValueError(f"descriptors must be (n, {self.descriptor_length}) float32")
         idx = np.zeros((len(a), 2), np.int32)
         dist = np.zeros((len(a), 2), np.float32)
         self._chk(self.lib.vo_match_knn2(self._h, _p(a, f32p), len(a), _p(b, f32p), len(b), _p(idx, i32p), _p(dist, f32p)))
