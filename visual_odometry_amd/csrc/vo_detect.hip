@@ -2978,12 +2978,14 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
                 // keypoints whose window coordinates are not exact in closed form (list 4): sequential walk
                 StageScope sc(ctx, ST_DESC_SEQ);
                 // (more than three layers per octave: keypoint sizes up to 48 * n_octave_layers + 120, windows up to kHugeWin)
+                // (upright / extended send EVERY keypoint here: two workgroups per CU instead of one per CU)
+                const int seq_grid = (ctx->prm.upright || ctx->prm.extended) ? 512 : 256;
                 if (ctx->prm.n_octave_layers > kLayersPerOctave - 2)
-                    hipLaunchKernelGGL((k_describe<0, kHugeWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                    hipLaunchKernelGGL((k_describe<0, kHugeWin, 256>), dim3(seq_grid / 2), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                                        fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
                                        ctx->prm.upright ? 2 : 1, ctx->prm.extended);
                 else
-                    hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(256), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                    hipLaunchKernelGGL((k_describe<0, kBigWin, 256>), dim3(seq_grid), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                                        fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
                                        ctx->prm.upright ? 2 : 1, ctx->prm.extended);
             }
