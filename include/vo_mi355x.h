@@ -116,7 +116,8 @@ int vo_hessian_layer(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t
 
 /* The same det values as the PRODUCT kernels hold them (the fused Hessian + NMS launches of vo_detect_describe keep the five
  * planes of an octave in LDS and never write them out; this inspection call makes them store what their NMS reads).
- * det_all: all 20 layers packed octave-major, layer l of octave o is [rows >> o][cols >> o]; n_floats must be the total.   */
+ * det_all: all 20 layers packed octave-major, layer l of octave o is [rows >> o][cols >> o]; n_floats must be the total.
+ * VO_ERR_UNSUPPORTED for a context with other than the reference's 4 octaves x 3 layers (those run other kernels).          */
 int vo_hessian_product_det(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step,
                            float* det_all, size_t n_floats);
 

@@ -124,11 +124,23 @@ int main(int argc, char** argv) {
     opt_DetectFeatures(prev_img, curr_img, sparse);
     const bool hess_ok = sparse.Kpoints1.size() < n_all;
     minHessian = 50;
+    // the SURF constructor arguments (:35-38) are globals too: another layer count and 128-float descriptors must reach the library
+    // (different matches, not an error), and restoring them must restore the first result
+    nOctaveLayers = 4;
+    KpAsPoint2f_Match deeper;
+    opt_DetectFeatures(prev_img, curr_img, deeper);
+    nOctaveLayers = 3;
+    extended = true;
+    KpAsPoint2f_Match wide;
+    opt_DetectFeatures(prev_img, curr_img, wide);
+    extended = false;
+    const bool surf_ok = deeper.Kpoints1.size() > 50 && deeper.Kpoints1.size() != n_all && wide.Kpoints1.size() > 20 && wide.Kpoints1.size() != n_all;
     KpAsPoint2f_Match again;
     opt_DetectFeatures(prev_img, curr_img, again);
     bool same = again.Kpoints1.size() == n_all;
     for (size_t i = 0; same && i < n_all; i++) same = again.Kpoints1[i].x == kP_converted.Kpoints1[i].x && again.Kpoints2[i].y == kP_converted.Kpoints2[i].y;
-    printf("globals: roi %s (%zu of %zu matches right of x = 300) minHessian %s (%zu matches at 5000) restored %s\n", roi_ok ? "ok" : "BAD",
-           narrow.Kpoints1.size(), n_all, hess_ok ? "ok" : "BAD", sparse.Kpoints1.size(), same ? "ok" : "BAD");
-    return kP_converted.Kpoints1.size() > 50 && roi_ok && hess_ok && same ? 0 : 1;
+    printf("globals: roi %s (%zu of %zu matches right of x = 300) minHessian %s (%zu matches at 5000) nOctaveLayers / extended %s (%zu / %zu matches) restored %s\n",
+           roi_ok ? "ok" : "BAD", narrow.Kpoints1.size(), n_all, hess_ok ? "ok" : "BAD", sparse.Kpoints1.size(), surf_ok ? "ok" : "BAD",
+           deeper.Kpoints1.size(), wide.Kpoints1.size(), same ? "ok" : "BAD");
+    return kP_converted.Kpoints1.size() > 50 && roi_ok && hess_ok && surf_ok && same ? 0 : 1;
 }

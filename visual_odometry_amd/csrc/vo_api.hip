@@ -437,6 +437,8 @@ extern "C" int vo_hessian_layer(vo_ctx* ctx, const uint8_t* img, int rows, int c
 extern "C" int vo_hessian_product_det(vo_ctx* ctx, const uint8_t* img, int rows, int cols, size_t step, float* det_all,
                                       size_t n_floats) {
     if (!ctx || !det_all) return VO_ERR_INVALID_ARG;
+    // the inspection reads the LDS planes of the tuned kernels: five layers per octave, all four octaves
+    if (ctx->prm.n_octave_layers != kLayersPerOctave - 2 || ctx->prm.n_octaves != kNumOctaves) return VO_ERR_UNSUPPORTED;
     VO_TRY(check_image(img, rows, cols, step));
     size_t S = 0;
     for (int o = 0; o < kNumOctaves; o++) S += (size_t)kLayersPerOctave * (rows >> o) * (cols >> o);
