@@ -366,6 +366,8 @@ def test_octave_layer_variants(ctx, n_layers, n_oct, upright):
     c = Context(p)
     try:
         frames = [_scene(480, 640, 700, 1001).img1, _scene(243, 322, 150, 11).img1, _wide_blob_frame(1080, 1440, 60, 40 + n_layers)]
+        if n_layers == 6:  # very wide blobs: keypoints of octave 3's top layers, windows of ~1000 pixels
+            frames.append(_wide_blob_frame(1300, 1700, 25, 1, 48.0, 75.0))
         big = 0
         for img in frames:
             k, d = c.detect_describe(img)
@@ -381,6 +383,8 @@ def test_octave_layer_variants(ctx, n_layers, n_oct, upright):
             _assert_kps_equal(k0, rk0)
         if n_layers >= 5 and n_oct == 4:
             assert big > 0, "no window beyond the tiled kernels' tables was exercised"
+        if n_layers == 6:
+            assert _window_sizes(k).max() > 1000
         # a second call on the same context (the det-plane buffer is reused) and a context-level pair call
         k2, d2 = c.detect_describe(frames[0])
         rk2, rd2 = O.detect_describe(frames[0], params=p)

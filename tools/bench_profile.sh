@@ -12,5 +12,5 @@ for f in ("gpurun_out/bench_line.json", "gpurun_out/bench_prof_line.json"):
     for l in open(f):
         if l.startswith("{"):
             d = json.loads(l)
-            print(f, d["value"], d["ms_per_step"], d["pcie_inclusive"]["value"], d["cpu_baseline"], d["roofline"]["kernel"], d["roofline"]["frac"], d["match_exact_scans_per_step"])
+            print(f, d["value"], d["ms_per_step"], d.get("resident", {}).get("value"), d.get("cpu_baseline"), d["roofline"]["kernel"], d["roofline"]["frac"], d.get("match_exact_scans_per_step"))
 PY
