@@ -34,7 +34,7 @@ typedef enum vo_status {
     VO_ERR_NO_DEVICE = -2,     /* no HIP device / not gfx950 / device index out of range */
     VO_ERR_HIP = -3,           /* a HIP runtime call failed (see vo_last_hip_error)   */
     VO_ERR_CAPACITY = -4,      /* an output did not fit the caller's capacity          */
-    VO_ERR_UNSUPPORTED = -5,   /* parameter value not implemented (e.g. n_octaves > 4) */
+    VO_ERR_UNSUPPORTED = -5,   /* parameter value not implemented (e.g. n_octaves > 5) */
     VO_ERR_TOO_FEW_POINTS = -6,/* fewer than 5 correspondences (findEssentialMat fails)*/
     VO_ERR_NO_MODEL = -7       /* RANSAC found no model with more than 4 inliers       */
 } vo_status;
@@ -68,7 +68,8 @@ typedef enum vo_fail { VO_FAIL_DETECTION = 0, VO_NOT_MOVING = 1, VO_FAIL_RECOVER
  */
 typedef struct vo_params {
     float hessian_threshold;      /* minHessian = 50                       :33 */
-    int32_t n_octaves;            /* 4 (1..4 accepted)                     :35 */
+    int32_t n_octaves;            /* 4 (1..5 accepted; a fifth octave runs :35
+                                     plain kernels, with <= 3 layers only)    */
     int32_t n_octave_layers;      /* 3 (1..6 accepted; other than 3: plain :36
                                      det-plane / NMS kernels)                 */
     int32_t extended;             /* false = 64 floats per descriptor;     :37

@@ -430,11 +430,47 @@ def test_extended_descriptors(ctx, n_layers, upright):
         c64.close()
 
 
+@pytest.mark.parametrize("upright,extended", [(0, 0), (1, 0), (0, 1)])
+def test_fifth_octave(ctx, upright, extended):
+    """vo_params.n_octaves = 5 (camera_utility.hpp:35 is a mutable global; the reference leaves it at 4): octaves 0 - 3 run the
+    tuned launches, octave 4 (layers of 144 ... 528 pixels, sampled every 16th pixel) the plain det-plane / NMS kernels, its
+    keypoints' windows of up to 1478 pixels the largest instance of the sequential describer.  Against the oracle; and the
+    keypoints of octaves 0 - 3 are those of the four-octave run."""
+    from visual_odometry_amd.frontend import Context, default_params
+
+    p = default_params()
+    p.n_octaves, p.upright, p.extended = 5, upright, extended
+    c = Context(p)
+    try:
+        widest, n_oct4 = 0, 0
+        for img in (_scene(480, 640, 700, 1001).img1, _wide_blob_frame(1500, 2000, 20, 1, 60.0, 100.0), _wide_blob_frame(1100, 1500, 40, 3, 20.0, 100.0)):
+            k, d = c.detect_describe(img)
+            rk, rd = O.detect_describe(img, params=p)
+            _assert_kps_equal(k, rk)
+            assert np.array_equal(k["angle"].view(np.uint32), rk["angle"].view(np.uint32))
+            bad = np.flatnonzero((d.view(np.uint32) != rd.view(np.uint32)).any(axis=1))
+            assert len(bad) == 0, (len(bad), len(k), bad[:10], _window_sizes(k)[bad[:10]])
+            widest = max(widest, int(_window_sizes(k).max()))
+            n_oct4 += int((k["octave"] == 4).sum())
+            if not upright and not extended:
+                k4, d4 = ctx.detect_describe(img)
+                keep = k["octave"] < 4
+                _assert_kps_equal(k[keep], k4)
+                assert np.array_equal(d[keep].view(np.uint32), d4.view(np.uint32))
+        assert widest > 1152 and n_oct4 > 5
+    finally:
+        c.close()
+
+
 def test_unsupported_surf_variants_are_refused():
     from visual_odometry_amd.frontend import Context, VoError, default_params
 
-    for field, value in (("n_octave_layers", 0), ("n_octave_layers", 7), ("n_octaves", 5), ("n_octaves", 0)):
+    for field, value in (("n_octave_layers", 0), ("n_octave_layers", 7), ("n_octaves", 6), ("n_octaves", 0)):
         p = default_params()
         setattr(p, field, value)
         with pytest.raises(VoError):
             Context(p)
+    p = default_params()
+    p.n_octaves, p.n_octave_layers = 5, 4  # a fifth octave only with at most three layers (window size)
+    with pytest.raises(VoError):
+        Context(p)

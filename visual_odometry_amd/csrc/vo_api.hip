@@ -221,9 +221,12 @@ extern "C" int vo_ctx_create(const vo_params* params, int hip_device, vo_ctx** o
         p = *params;
     else
         vo_params_default(&p);
-    // the reference's values (4, 3, false, false) take the tuned kernels; fewer octaves, 1..6 layers per octave, upright and
+    // the reference's values (4, 3, false, false) take the tuned kernels; 1..5 octaves, 1..6 layers per octave, upright and
     // extended (128-float descriptors) take plain forms of the same arithmetic
-    if (p.n_octaves < 1 || p.n_octaves > 4 || p.n_octave_layers < 1 || p.n_octave_layers > kMaxOctaveLayers) return VO_ERR_UNSUPPORTED;
+    // (a fifth octave doubles the largest window once more: accepted with at most the reference's three layers)
+    if (p.n_octaves < 1 || p.n_octaves > kMaxOctaves || p.n_octave_layers < 1 || p.n_octave_layers > kMaxOctaveLayers ||
+        (p.n_octaves > kNumOctaves && p.n_octave_layers > kLayersPerOctave - 2))
+        return VO_ERR_UNSUPPORTED;
     p.upright = p.upright ? 1 : 0;
     p.extended = p.extended ? 1 : 0;
     if (p.kp_capacity < 64 || p.match_capacity < 8 || p.ransac_max_iters < 1 || p.ransac_max_iters > kMaxHyp)

@@ -31,6 +31,7 @@ void vo_set_error_text(const char* text);  // what vo_last_hip_error() returns n
 constexpr int kNumOctaves = 4;
 constexpr int kLayersPerOctave = 5;  // nOctaveLayers + 2
 constexpr int kNumLayers = kNumOctaves * kLayersPerOctave;
+constexpr int kMaxOctaves = 5;       // vo_params.n_octaves 1..5 (octaves 0..3: the tuned kernels; a fifth: plain kernels, <= 3 layers)
 constexpr int kMaxOctaveLayers = 6;  // vo_params.n_octave_layers 1..6 (3 = the reference's, the LDS-tile kernels; others: plain kernels)
 constexpr int kOriSamples = 113;  // lattice points with i^2 + j^2 <= 36 (SURVEY A.5 says 109; the loop it quotes yields 113)
 constexpr int kPatch = 20;        // PATCH_SZ

@@ -1175,11 +1175,11 @@ __global__ __launch_bounds__(256) void k_nms_g(const float* __restrict__ det, si
     }
 }
 
-static int enqueue_hessian_nms_generic(vo_ctx* ctx, FrameSet& fs, bool describe) {
+static int enqueue_hessian_nms_generic(vo_ctx* ctx, FrameSet& fs, bool describe, int o_begin) {
     const int nl = ctx->prm.n_octave_layers, n_oct = ctx->prm.n_octaves;
     const int filter_mode = describe ? (ctx->prm.upright ? 2 : 1) : 0;
     // det planes of ONE octave for a group of frames; the buffer is bounded (2 GB) and grows with the context
-    const size_t per_frame0 = (size_t)(nl + 2) * fs.H * fs.W;  // floats, octave 0
+    const size_t per_frame0 = (size_t)(nl + 2) * (fs.H >> o_begin) * (fs.W >> o_begin);  // floats, the first (largest) octave
     if (per_frame0 == 0) return VO_OK;
     const size_t budget = (size_t)1 << 29;  // floats
     const int group = (int)std::min<size_t>((size_t)fs.F, std::max<size_t>(1, budget / per_frame0));
@@ -1195,7 +1195,7 @@ static int enqueue_hessian_nms_generic(vo_ctx* ctx, FrameSet& fs, bool describe)
     StageScope sc(ctx, ST_HESSIAN_OCT0);
     for (int f0 = 0; f0 < fs.F; f0 += group) {
         const int nf = std::min(group, fs.F - f0);
-        for (int o = 0; o < n_oct; o++) {
+        for (int o = o_begin; o < n_oct; o++) {
             const int step = 1 << o, lrows = fs.H / step, lcols = fs.W / step;
             if (lrows <= 0 || lcols <= 0) continue;
             const size_t plane = (size_t)lrows * lcols, frame_stride = plane * (nl + 2);
@@ -1338,6 +1338,7 @@ __global__ __launch_bounds__(1024) void k_sort_bitonic(const vo_keypoint* __rest
 constexpr int kSmallWin = 128;  // windows up to 128 px use the 11 KB LDS instance
 constexpr int kMidWin = 320;
 constexpr int kBigWin = 768;    // largest window: 21 * 1.2/9 * (216 + 48) = 739
+constexpr int kOct5Win = 1536;  // n_octaves = 5 (with at most three layers): 21 * 1.2/9 * (432 + 96) = 1478 (sequential kernel only)
 constexpr int kHugeWin = 1152;  // n_octave_layers up to kMaxOctaveLayers = 6: 21 * 1.2/9 * (360 + 48) = 1142 (sequential kernel only)
 
 struct CellTab {  // one destination cell of the INTER_AREA decimation table
@@ -2808,7 +2809,7 @@ __global__ __launch_bounds__(256) void k_classify_scatter(const vo_keypoint* __r
 // a2 + a3 of the product path: the two fused Hessian + NMS launches.  dbg_det (inspection only, otherwise null) receives the
 // det planes of frame 0 as the NMS reads them.
 int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_det) {
-    if (ctx->prm.n_octave_layers != kLayersPerOctave - 2) return enqueue_hessian_nms_generic(ctx, fs, describe);
+    if (ctx->prm.n_octave_layers != kLayersPerOctave - 2) return enqueue_hessian_nms_generic(ctx, fs, describe, 0);
     DetectGeom g;
     g.H = fs.H;
     g.W = fs.W;
@@ -2827,7 +2828,7 @@ int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_
         DetectGeom g2 = g;
         g2.tiles_x[0] = g2.tiles_y[0] = g2.tiles_x[1] = g2.tiles_y[1] = 0;
         // fewer than the reference's four octaves (vo_params.n_octaves): the octaves are independent, the dropped ones are not launched
-        const int n_oct = ctx->prm.n_octaves;
+        const int n_oct = std::min(ctx->prm.n_octaves, kNumOctaves);
         for (int o = n_oct; o < kNumOctaves; o++) g2.tiles_x[o] = g2.tiles_y[o] = 0;
         // keypoints the describer would delete are dropped here: 1 = the reference's two tests, 2 = upright (the first test only)
         const int filter_mode = describe ? (ctx->prm.upright ? 2 : 1) : 0;
@@ -2865,6 +2866,9 @@ int vo_enqueue_hessian_nms(vo_ctx* ctx, FrameSet& fs, bool describe, float* dbg_
         }
         VO_HIP(hipGetLastError());
     }
+    // a fifth octave (vo_params.n_octaves = 5; the reference has 4, camera_utility.hpp:35): the plain kernels after the tuned
+    // launches of octaves 0 - 3, on the main stream; they append to the same lists
+    if (ctx->prm.n_octaves > kNumOctaves) VO_TRY(enqueue_hessian_nms_generic(ctx, fs, describe, kNumOctaves));
     return VO_OK;
 }
 
@@ -2980,7 +2984,11 @@ int vo_enqueue_detect(vo_ctx* ctx, FrameSet& fs, bool describe, bool integral_be
                 // (more than three layers per octave: keypoint sizes up to 48 * n_octave_layers + 120, windows up to kHugeWin)
                 // (upright / extended send EVERY keypoint here: two workgroups per CU instead of one per CU)
                 const int seq_grid = (ctx->prm.upright || ctx->prm.extended) ? 512 : 256;
-                if (ctx->prm.n_octave_layers > kLayersPerOctave - 2)
+                if (ctx->prm.n_octaves > kNumOctaves)  // sizes up to 528, windows up to 1478: 150 KB of LDS
+                    hipLaunchKernelGGL((k_describe<0, kOct5Win, 256>), dim3(seq_grid / 2), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
+                                       fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
+                                       ctx->prm.upright ? 2 : 1, ctx->prm.extended);
+                else if (ctx->prm.n_octave_layers > kLayersPerOctave - 2)
                     hipLaunchKernelGGL((k_describe<0, kHugeWin, 256>), dim3(seq_grid / 2), dim3(256), 0, ctx->stream, fs.img, fs.img_stride(),
                                        fs.sum, fs.sum_stride(), fs.H, fs.W, fs.kp, d, fs.cap, fs.cls_list + (size_t)4 * ls, fs.cls_cnt, 4,
                                        ctx->prm.upright ? 2 : 1, ctx->prm.extended);
