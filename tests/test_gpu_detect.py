@@ -221,6 +221,32 @@ def test_frames_smaller_than_the_filters(ctx, shape):
         assert len(k) >= 1
 
 
+@pytest.mark.parametrize("n_oct,n_layers,extended", [(5, 3, 0), (4, 6, 0), (4, 1, 1), (2, 5, 0)])
+def test_small_frames_with_surf_variants(n_oct, n_layers, extended):
+    """The plain det-plane / NMS kernels (other layer counts, a fifth octave) on frames in which most layers do not fit and whole
+    octaves have no sample: the oracle's keypoints and descriptors, nothing out of bounds."""
+    from visual_odometry_amd.frontend import Context, default_params
+
+    p = default_params()
+    p.n_octaves, p.n_octave_layers, p.extended = n_oct, n_layers, extended
+    c = Context(p)
+    try:
+        total = 0
+        for shape in [(97, 131), (64, 64), (40, 30), (21, 33), (16, 16), (150, 17)]:
+            rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+            img = np.clip(rng.normal(128, 60, size=shape), 0, 255).astype(np.uint8)
+            yy, xx = np.mgrid[: shape[0], : shape[1]]
+            img = np.clip(img.astype(np.float32) * 0.3 + 160 * np.exp(-((yy - shape[0] / 2) ** 2 + (xx - shape[1] / 2) ** 2) / 18.0), 0, 255).astype(np.uint8)
+            k, d = c.detect_describe(img)
+            rk, rd = O.detect_describe(img, params=p)
+            _assert_kps_equal(k, rk)
+            assert np.array_equal(d.view(np.uint32), rd.view(np.uint32))
+            total += len(k)
+        assert total > 5
+    finally:
+        c.close()
+
+
 def test_capacity_error(ctx):
     from visual_odometry_amd.frontend import VoError
 
