@@ -2,10 +2,13 @@
 16 synthetic 1080p pairs (synth.scene_c2) per run, frames resident, median of 5 runs after a warm-up.  The reference's values
 (4, 3, false, false) take the tuned kernels; every other value takes a plain form of the same arithmetic."""
 import json
+import os
 import sys
 import time
 
 import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 from visual_odometry_amd import synth
 from visual_odometry_amd.frontend import Batch, Context, default_params
@@ -16,7 +19,7 @@ def main():
     scenes = [synth.scene_c2(2002 + i) for i in range(4)]
     out = []
     for name, kw in [("reference (4, 3, false, false)", {}), ("n_octaves=3", {"n_octaves": 3}), ("n_octave_layers=2", {"n_octave_layers": 2}),
-                     ("n_octave_layers=4", {"n_octave_layers": 4}), ("n_octave_layers=6", {"n_octave_layers": 6}), ("upright", {"upright": 1}),
+                     ("n_octave_layers=4", {"n_octave_layers": 4}), ("n_octave_layers=6", {"n_octave_layers": 6}), ("n_octaves=5", {"n_octaves": 5}), ("upright", {"upright": 1}),
                      ("extended", {"extended": 1})]:
         p = default_params()
         for k, v in kw.items():
