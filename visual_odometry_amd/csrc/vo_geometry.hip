@@ -1527,7 +1527,10 @@ int vo_enqueue_geometry(vo_ctx* ctx, PairSet& ps, const GeoOptions& o, hipStream
         // Past 256 hypotheses everything that is left goes out as ONE launch: a chunk costs a wavefront's lifetime (~0.1 - 0.3 ms)
         // whatever its size, and wavefronts past the bound the scans have reached by then leave at once.  (If the bound drops
         // inside that chunk the hypotheses behind it were solved for nothing; the in-order scan ignores them.)
-        const int bounds[5] = {0, P >= 8 ? 16 : 64, 64, 256, kMaxHyp};
+        // A few pairs (the synchronous calls: one pair) never fill the chip - 1024 hypotheses are one wavefront per SIMD - so a
+        // further chunk boundary buys nothing there and costs a wavefront's lifetime: 64, then everything
+        // (configs[4], one pair x 4096 hypotheses x 8192 matches: 2.03 -> 1.54 ms).
+        const int bounds[5] = {0, P >= 8 ? 16 : 64, 64, P >= 8 ? 256 : 64, kMaxHyp};
         for (int c = 0; c < 4; c++) {
             const int h0 = bounds[c], h1 = std::min(bounds[c + 1], o.max_iters);
             if (h0 >= h1) continue;  // an empty chunk (a single pair's second bound) or past max_iters
